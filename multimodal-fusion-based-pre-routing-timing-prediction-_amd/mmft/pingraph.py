@@ -1,0 +1,200 @@
+"""PinGraph: the graph container the hot path consumes.
+
+The reference passes a DGL heterograph with node type 'pin' and edge types 'net' / 'cell'
+(src/dataset.py:274-287) and touches only a small accessor surface from the loops
+(src/train.py:342-348,467,513-521,559-561; src/model.py:206-213):
+
+    graph.ndata[...]                    graph.nodes['pin'].data[...]
+    graph.edges['cell'].data[...]       graph.number_of_nodes()
+    graph.number_of_edges(etype=...)    graph.to(device)
+
+DGL has no ROCm build in this image, so PinGraph offers the same surface and additionally
+owns what the HIP kernels need: in-edge CSR and out-edge CSR per edge type (int32, device
+resident), cached per-level row lists, and the per-sweep scratch state.
+"""
+import numpy as np
+import torch
+
+ETYPES = ('net', 'cell')
+
+
+class _NodeView:
+    def __init__(self, data):
+        self.data = data
+
+
+class _Accessor:
+    def __init__(self, table):
+        self._t = table
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple):
+            key = key[1]
+        return self._t[key]
+
+
+def _csr_from_coo(n, rows, cols):
+    """CSR over `rows` (stable, keeps insertion order inside a row). Returns indptr, cols, perm."""
+    rows = np.asarray(rows, dtype=np.int64)
+    cols = np.asarray(cols, dtype=np.int64)
+    perm = np.argsort(rows, kind='stable')
+    counts = np.bincount(rows, minlength=n)
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(counts, out=indptr[1:])
+    return indptr, cols[perm], perm
+
+
+class PinGraph:
+    def __init__(self, num_nodes, edges):
+        """edges: {'net': (src, dst), 'cell': (src, dst)} as array-likes of node ids."""
+        self._n = int(num_nodes)
+        self._coo = {}
+        for et in ETYPES:
+            s, d = edges.get(et, ((), ()))
+            s = np.asarray(torch.as_tensor(s).cpu().numpy() if torch.is_tensor(s) else s, dtype=np.int64)
+            d = np.asarray(torch.as_tensor(d).cpu().numpy() if torch.is_tensor(d) else d, dtype=np.int64)
+            assert s.shape == d.shape
+            if s.size:
+                assert s.min() >= 0 and d.min() >= 0 and max(s.max(), d.max()) < self._n, "edge id out of range"
+            self._coo[et] = (s, d)
+        self.device = torch.device('cpu')
+        self._ndata = {}
+        self._edata = {et: {} for et in ETYPES}
+        self._csr_host = {}
+        self._csr_dev = {}
+        self._level_cache = {}
+        self._sweep = None          # per-sweep state, owned by mmft.sweep
+        self._build_csr()
+
+    # ------------------------------------------------------------------ DGL-like surface
+    @property
+    def ndata(self):
+        return self._ndata
+
+    @property
+    def nodes(self):
+        return _Accessor({'pin': _NodeView(self._ndata)})
+
+    @property
+    def edges(self):
+        return _Accessor({et: _NodeView(self._edata[et]) for et in ETYPES})
+
+    @property
+    def ntypes(self):
+        return ['pin']
+
+    @property
+    def etypes(self):
+        return list(ETYPES)
+
+    def number_of_nodes(self, ntype=None):
+        return self._n
+
+    num_nodes = number_of_nodes
+
+    def number_of_edges(self, etype=None):
+        if etype is None:
+            return sum(self._coo[et][0].shape[0] for et in ETYPES)
+        if isinstance(etype, tuple):
+            etype = etype[1]
+        return int(self._coo[etype][0].shape[0])
+
+    num_edges = number_of_edges
+
+    def to(self, device):
+        device = torch.device(device)
+        g = PinGraph.__new__(PinGraph)
+        g._n = self._n
+        g._coo = self._coo
+        g.device = device
+        g._ndata = {k: v.to(device) for k, v in self._ndata.items()}
+        g._edata = {et: {k: v.to(device) for k, v in self._edata[et].items()} for et in ETYPES}
+        g._csr_host = self._csr_host
+        g._csr_dev = {}
+        g._level_cache = {}
+        g._sweep = None
+        return g
+
+    def in_degrees(self, etype):
+        ip = self._csr_host[('in', etype)][0]
+        return torch.from_numpy(np.diff(ip))
+
+    # ------------------------------------------------------------------ CSR for the kernels
+    def _build_csr(self):
+        for et in ETYPES:
+            s, d = self._coo[et]
+            ip, src_sorted, perm = _csr_from_coo(self._n, d, s)       # in-edges: row = dst, col = src
+            self._csr_host[('in', et)] = (ip, src_sorted, perm)
+            op, dst_sorted, operm = _csr_from_coo(self._n, s, d)      # out-edges: row = src, col = dst
+            self._csr_host[('out', et)] = (op, dst_sorted, operm)
+
+    def csr(self, direction, etype):
+        """(indptr int32[N+1], indices int32[E]) on self.device; cached."""
+        key = (direction, etype)
+        if key not in self._csr_dev:
+            ip, idx, _ = self._csr_host[key]
+            assert ip[-1] < 2 ** 31, "edge count exceeds int32"
+            self._csr_dev[key] = (torch.from_numpy(ip.astype(np.int32)).to(self.device),
+                                  torch.from_numpy(idx.astype(np.int32)).to(self.device))
+        return self._csr_dev[key]
+
+    def csr_host(self, direction, etype):
+        ip, idx, _ = self._csr_host[(direction, etype)]
+        return ip, idx
+
+    def level_rows(self, level_id, nodes, tag='nodes'):
+        """Device int32 tensor of a level's node list; cached by (tag, level_id).
+
+        `cur_nodes` / `targets` arrive as python int lists on every call
+        (src/train.py:491-503); re-uploading them per call is what the cache avoids.
+        """
+        key = (tag, level_id)
+        hit = self._level_cache.get(key)
+        if hit is not None:
+            ref, dev = hit
+            if ref is nodes or (len(ref) == len(nodes) and ref == nodes):
+                return dev
+        if torch.is_tensor(nodes):
+            host = nodes.detach().to('cpu', torch.int64)
+            ref = host.tolist()
+        else:
+            ref = nodes
+            host = torch.tensor(nodes, dtype=torch.int64) if len(nodes) else torch.zeros(0, dtype=torch.int64)
+        if host.numel():
+            assert int(host.min()) >= 0 and int(host.max()) < self._n, "node id out of range"
+        dev = host.to(torch.int32).to(self.device)
+        self._level_cache[key] = (ref, dev)
+        return dev
+
+    # ------------------------------------------------------------------ construction helpers
+    @staticmethod
+    def from_synth(d, out_dim=None):
+        """PinGraph + ndata laid out as src/dataset.py:280-287 / src/train.py:342-343."""
+        g = PinGraph(d.N, {'net': (d.net_src, d.net_dst), 'cell': (d.cell_src, d.cell_dst)})
+        g.ndata['cell_feat'] = torch.from_numpy(d.cell_feat)
+        g.ndata['net_feat'] = torch.from_numpy(d.net_feat)
+        g.ndata['arrival_time'] = torch.from_numpy(d.arrival_time)
+        g.ndata['required_time'] = torch.from_numpy(d.required_time)
+        g.ndata['label'] = torch.from_numpy(d.label)
+        g.ndata['end'] = torch.from_numpy(d.is_end)
+        if out_dim is not None:
+            g.ndata['h'] = torch.zeros((d.N, out_dim), dtype=torch.float32)
+        return g
+
+    @staticmethod
+    def batch(graphs):
+        """Block-diagonal merge (node ids offset by the running node count)."""
+        off = 0
+        coo = {et: ([], []) for et in ETYPES}
+        for g in graphs:
+            for et in ETYPES:
+                s, d = g._coo[et]
+                coo[et][0].append(s + off)
+                coo[et][1].append(d + off)
+            off += g._n
+        merged = PinGraph(off, {et: (np.concatenate(coo[et][0]), np.concatenate(coo[et][1])) for et in ETYPES})
+        keys = set(graphs[0].ndata.keys())
+        for k in keys:
+            if all(k in g.ndata for g in graphs):
+                merged.ndata[k] = torch.cat([g.ndata[k] for g in graphs], dim=0)
+        return merged
