@@ -1,0 +1,55 @@
+// Shared helpers for libmmft_hip.so (gfx950 / CDNA4 only; wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/mmft.h"
+
+namespace mmft {
+
+void set_error(const char* fmt, ...);
+
+struct DeviceGuard {
+  int prev;
+  bool switched;
+  explicit DeviceGuard(int dev) : prev(-1), switched(false) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
+      switched = (hipSetDevice(dev) == hipSuccess);
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return MMFT_ERR_LAUNCH;
+  }
+  return MMFT_OK;
+}
+
+#define MMFT_REQUIRE(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      mmft::set_error(__VA_ARGS__);        \
+      return MMFT_ERR_BAD_ARG;             \
+    }                                      \
+  } while (0)
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// grid for memory-bound elementwise work: cap at ~8 blocks/CU and grid-stride the rest
+inline int ew_grid(long long work_items, int block = 256) {
+  long long g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > 256 * 8) g = 256 * 8;
+  return (int)g;
+}
+
+}  // namespace mmft

@@ -1,0 +1,404 @@
+// fp32 MFMA GEMM engine for gfx950:  C[m][n] = epilogue( sum_k X[m][k] * Wt[n][k] ).
+//
+// One engine serves every dense contraction on the hot path (level MLPs K4, fusion MLP K9, dense
+// fcn K7, conv / dgrad / wgrad K11, convT K14) through pluggable operand loaders:
+//   * "MK" operands are k-contiguous in memory  (activations [row][feature], weights [out][in]);
+//   * "KM" operands are m-contiguous in memory  (dY for wgrad, W[out][in] read as [k=out][n=in]).
+// Each operand is copied into LDS in its natural order (16-B global loads, 16-B LDS stores) and read
+// back as MFMA fragments: MK tiles with one ds_read_b128 per 16-deep k block (the four dwords feed
+// four consecutive v_mfma_f32_16x16x4_f32 steps; lane quarter q owns k = 4q..4q+3, the same
+// permutation on both operands, so the sum over k is complete), KM tiles with ds_read_b32.
+// LDS row strides are chosen conflict-free for those reads (MK: BK+8 dwords == 8 mod 16;
+// KM: BM+4 dwords, so that the four k rows of a 32-lane group fall on disjoint bank halves).
+//
+// MFMA roles: the weight-side operand is MFMA "A" (index i), the row-side operand is MFMA "B"
+// (index j).  The 16x16 accumulator then holds, per lane, FOUR CONSECUTIVE n for ONE m
+// (n = 4*(lane>>4)+r, m = lane&15), i.e. every lane ends with a 16-byte store along the
+// contiguous dimension of the row-major output.
+//
+// Exact fp32: v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain (guide §3 "FP32-input MFMA").
+#pragma once
+#include "common.h"
+
+namespace mmft {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int BM_, int BN_, int BK_, int WM_, int WN_>
+struct TileCfg {
+  static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
+  static_assert(WM_ * WN_ == 4, "4 waves per workgroup");
+  static_assert(BM_ % (16 * WM_) == 0 && BN_ % (16 * WN_) == 0, "tile/wave mismatch");
+};
+
+// ------------------------------------------------------------------------------------ loaders
+// MK loaders: ctx(m) once per thread-row, load(ctx, k, kend) -> X[m][k..k+3] (zero beyond kend/rows)
+// KM loaders: ctx(m4) once per thread-column group, load(ctx, k, kend) -> X[k][m..m+3]
+
+struct DenseMK {
+  static constexpr bool KMAJOR = false;
+  const float* p;
+  const int* idx;  // optional row gather
+  long long ld;
+  int rows;
+  int vec;  // 16-B loads legal (ld % 4 == 0, base aligned)
+  struct Ctx {
+    const float* row;
+  };
+  __device__ __forceinline__ Ctx ctx(int m) const {
+    Ctx c;
+    if (m >= rows) {
+      c.row = nullptr;
+    } else {
+      long long r = idx ? (long long)idx[m] : (long long)m;
+      c.row = p + r * ld;
+    }
+    return c;
+  }
+  __device__ __forceinline__ f32x4 load(const Ctx& c, int k, int kend) const {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c.row == nullptr || k >= kend) return v;
+    if (vec && k + 3 < kend) return *reinterpret_cast<const f32x4*>(c.row + k);
+    v.x = c.row[k];
+    if (k + 1 < kend) v.y = c.row[k + 1];
+    if (k + 2 < kend) v.z = c.row[k + 2];
+    if (k + 3 < kend) v.w = c.row[k + 3];
+    return v;
+  }
+};
+
+struct DenseKM {
+  static constexpr bool KMAJOR = true;
+  const float* p;
+  const int* kidx;  // optional gather on the reduction rows
+  long long ld;
+  int cols;
+  int vec;
+  struct Ctx {
+    int m;
+  };
+  __device__ __forceinline__ Ctx ctx(int m) const { return Ctx{m}; }
+  __device__ __forceinline__ f32x4 load(const Ctx& c, int k, int kend) const {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (k >= kend || c.m >= cols) return v;
+    long long r = kidx ? (long long)kidx[k] : (long long)k;
+    const float* q = p + r * ld + c.m;
+    if (vec && c.m + 3 < cols) return *reinterpret_cast<const f32x4*>(q);
+    v.x = q[0];
+    if (c.m + 1 < cols) v.y = q[1];
+    if (c.m + 2 < cols) v.z = q[2];
+    if (c.m + 3 < cols) v.w = q[3];
+    return v;
+  }
+};
+
+// NHWC implicit-GEMM A operand: X[m = pixel][k = (tap, ci)], C % 4 == 0
+struct Im2colMK {
+  static constexpr bool KMAJOR = false;
+  const float* p;
+  int H, W, C, KH, KW, pad;
+  int rows;  // Nimg*H*W
+  struct Ctx {
+    int pix0, y, x;
+  };
+  __device__ __forceinline__ Ctx ctx(int m) const {
+    Ctx c;
+    if (m >= rows) {
+      c.pix0 = 0;
+      c.y = -(1 << 20);
+      c.x = 0;
+      return c;
+    }
+    int hw = H * W;
+    int img = m / hw;
+    int rem = m - img * hw;
+    c.y = rem / W;
+    c.x = rem - c.y * W;
+    c.pix0 = img * hw;
+    return c;
+  }
+  __device__ __forceinline__ f32x4 load(const Ctx& c, int k, int kend) const {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (k >= kend) return v;
+    int tap = k / C;
+    int ci = k - tap * C;
+    int ky = tap / KW;
+    int kx = tap - ky * KW;
+    int yy = c.y + ky - pad, xx = c.x + kx - pad;
+    if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) return v;
+    return *reinterpret_cast<const f32x4*>(p + ((long long)(c.pix0 + yy * W + xx)) * C + ci);
+  }
+};
+
+// wgrad B operand: X[k = pixel][n = (tap, ci)] gathered from the NHWC input, C % 4 == 0
+struct Im2colKM {
+  static constexpr bool KMAJOR = true;
+  const float* p;
+  int H, W, C, KH, KW, pad;
+  int cols;  // KH*KW*C
+  struct Ctx {
+    int dy, dx, ci;
+  };
+  __device__ __forceinline__ Ctx ctx(int n) const {
+    Ctx c;
+    if (n >= cols) {
+      c.ci = -1;
+      c.dy = c.dx = 0;
+      return c;
+    }
+    int tap = n / C;
+    c.ci = n - tap * C;
+    int ky = tap / KW;
+    c.dy = ky - pad;
+    c.dx = tap - ky * KW - pad;
+    return c;
+  }
+  __device__ __forceinline__ f32x4 load(const Ctx& c, int k, int kend) const {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (k >= kend || c.ci < 0) return v;
+    int hw = H * W;
+    int img = k / hw;
+    int rem = k - img * hw;
+    int y = rem / W;
+    int x = rem - y * W;
+    int yy = y + c.dy, xx = x + c.dx;
+    if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) return v;
+    return *reinterpret_cast<const f32x4*>(p + ((long long)(img * hw + yy * W + xx)) * C + c.ci);
+  }
+};
+
+// ------------------------------------------------------------------------------------ epilogue
+enum { EPI_STORE = 0, EPI_ACCUM = 1, EPI_ADD_ACT = 2, EPI_MASK = 3 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
+
+struct Epi {
+  float* C;
+  long long ldc;
+  const int* rowidx;   // optional row scatter
+  const float* bias;   // optional [N]
+  const float* mask;   // EPI_MASK: keep v where mask[maskrow][n] > 0
+  const int* maskidx;
+  long long ldmask;
+  int mode, act;
+  float slope;
+  long long slab;      // split-K: C + z*slab
+  int vec;
+
+  __device__ __forceinline__ float activate(float v) const {
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACT_LEAKY) return v > 0.f ? v : v * slope;
+    return v;
+  }
+  __device__ __forceinline__ void store(int m, int n, f32x4 v, int M, int N, int z) const {
+    if (m >= M || n >= N) return;
+    long long r = rowidx ? (long long)rowidx[m] : (long long)m;
+    float* q = C + (long long)z * slab + r * ldc + n;
+    float vv[4] = {v.x, v.y, v.z, v.w};
+    int cnt = N - n < 4 ? N - n : 4;
+    const float* mk = nullptr;
+    if (mode == EPI_MASK) {
+      long long mr = maskidx ? (long long)maskidx[m] : (long long)m;
+      mk = mask + mr * ldmask + n;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < cnt) {
+        float t = vv[j] + (bias ? bias[n + j] : 0.f);
+        if (mode == EPI_STORE) t = activate(t);
+        else if (mode == EPI_ACCUM) t += q[j];
+        else if (mode == EPI_ADD_ACT) t = activate(t + q[j]);
+        else t = mk[j] > 0.f ? t : 0.f;
+        vv[j] = t;
+      }
+    }
+    if (vec && cnt == 4) {
+      f32x4 o = {vv[0], vv[1], vv[2], vv[3]};
+      *reinterpret_cast<f32x4*>(q) = o;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < cnt) q[j] = vv[j];
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------ kernel
+template <bool KMAJOR, int S>
+__device__ __forceinline__ void read_frag(const float* tile, int row0, int kb, int lane, float (&f)[4]) {
+  if (!KMAJOR) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(tile + (row0 + (lane & 15)) * S + kb * 16 + (lane >> 4) * 4);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  } else {
+    const float* q = tile + (kb * 16 + 4 * (lane >> 4)) * S + row0 + (lane & 15);
+    f[0] = q[0]; f[1] = q[S]; f[2] = q[2 * S]; f[3] = q[3 * S];
+  }
+}
+
+template <class CFG, class XL, class WL>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(XL xl, WL wl, Epi epi, int M, int N, int K, int ksplit) {
+  constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, WM = CFG::WM, WN = CFG::WN;
+  constexpr int RT = BM / (16 * WM), FT = BN / (16 * WN);
+  constexpr int XS = XL::KMAJOR ? (BM + 4) : (BK + 8);
+  constexpr int WS = WL::KMAJOR ? (BN + 4) : (BK + 8);
+  constexpr int XSZ = XL::KMAJOR ? BK * XS : BM * XS;
+  constexpr int WSZ = WL::KMAJOR ? BK * WS : BN * WS;
+  constexpr int XG = BM * BK / 4, WG = BN * BK / 4;       // 16-byte groups per tile
+  constexpr int XN = (XG + 255) / 256, WNL = (WG + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (XSZ + WSZ)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int kbeg = blockIdx.z * ksplit;
+  const int kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  typename XL::Ctx xc[XN];
+  typename WL::Ctx wc[WNL];
+  int xk[XN], xo[XN], wk[WNL], wo[WNL];
+#pragma unroll
+  for (int i = 0; i < XN; ++i) {
+    int g = tid + i * 256;
+    if (XL::KMAJOR) {
+      int kk = g / (BM / 4), m4 = g % (BM / 4);
+      xc[i] = xl.ctx(m0 + m4 * 4);
+      xk[i] = kk;
+      xo[i] = kk * XS + m4 * 4;
+    } else {
+      int r = g / (BK / 4), k4 = g % (BK / 4);
+      xc[i] = xl.ctx(m0 + r);
+      xk[i] = k4 * 4;
+      xo[i] = r * XS + k4 * 4;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < WNL; ++i) {
+    int g = tid + i * 256;
+    if (WL::KMAJOR) {
+      int kk = g / (BN / 4), n4 = g % (BN / 4);
+      wc[i] = wl.ctx(n0 + n4 * 4);
+      wk[i] = kk;
+      wo[i] = kk * WS + n4 * 4;
+    } else {
+      int r = g / (BK / 4), k4 = g % (BK / 4);
+      wc[i] = wl.ctx(n0 + r);
+      wk[i] = k4 * 4;
+      wo[i] = r * WS + k4 * 4;
+    }
+  }
+
+  f32x4 acc[RT][FT];
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int b = 0; b < FT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x4 xr[XN], wr[WNL];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < XN; ++i)
+      if (XG % 256 == 0 || tid + i * 256 < XG) xr[i] = xl.load(xc[i], k0 + xk[i], kend);
+#pragma unroll
+    for (int i = 0; i < WNL; ++i)
+      if (WG % 256 == 0 || tid + i * 256 < WG) wr[i] = wl.load(wc[i], k0 + wk[i], kend);
+  };
+  auto lstore = [&](int buf) {
+    float* xs = lds + buf * (XSZ + WSZ);
+    float* ws = xs + XSZ;
+#pragma unroll
+    for (int i = 0; i < XN; ++i)
+      if (XG % 256 == 0 || tid + i * 256 < XG) *reinterpret_cast<f32x4*>(xs + xo[i]) = xr[i];
+#pragma unroll
+    for (int i = 0; i < WNL; ++i)
+      if (WG % 256 == 0 || tid + i * 256 < WG) *reinterpret_cast<f32x4*>(ws + wo[i]) = wr[i];
+  };
+
+  if (nk > 0) {
+    gload(kbeg);
+    lstore(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk) gload(kbeg + (t + 1) * BK);
+    const float* xs = lds + buf * (XSZ + WSZ);
+    const float* ws = xs + XSZ;
+#pragma unroll
+    for (int kb = 0; kb < BK / 16; ++kb) {
+      float xf[RT][4], wf[FT][4];
+#pragma unroll
+      for (int a = 0; a < RT; ++a) read_frag<XL::KMAJOR, XS>(xs, (wm * RT + a) * 16, kb, lane, xf[a]);
+#pragma unroll
+      for (int b = 0; b < FT; ++b) read_frag<WL::KMAJOR, WS>(ws, (wn * FT + b) * 16, kb, lane, wf[b]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int a = 0; a < RT; ++a)
+#pragma unroll
+          for (int b = 0; b < FT; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[b][s], xf[a][s], acc[a][b], 0, 0, 0);
+    }
+    if (t + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int b = 0; b < FT; ++b) {
+      int m = m0 + (wm * RT + a) * 16 + (lane & 15);
+      int n = n0 + (wn * FT + b) * 16 + (lane >> 4) * 4;
+      epi.store(m, n, acc[a][b], M, N, blockIdx.z);
+    }
+}
+
+// ------------------------------------------------------------------------------------ dispatch
+template <class CFG, class XL, class WL>
+inline void launch_cfg(const XL& xl, const WL& wl, const Epi& epi, int M, int N, int K, int splits, hipStream_t st) {
+  int ksplit = K;
+  if (splits > 1) {
+    int per = (K + splits - 1) / splits;
+    ksplit = ((per + CFG::BK - 1) / CFG::BK) * CFG::BK;
+    splits = (K + ksplit - 1) / ksplit;
+  }
+  dim3 grid(cdiv(M, CFG::BM), cdiv(N, CFG::BN), splits);
+  hipLaunchKernelGGL((gemm_f32_kernel<CFG, XL, WL>), grid, dim3(256), 0, st, xl, wl, epi, M, N, K, ksplit);
+}
+
+// number of split-K slabs launch_gemm will actually use for a requested count
+inline int effective_splits(int K, int splits) {
+  if (splits <= 1) return 1;
+  int per = (K + splits - 1) / splits;
+  int ksplit = ((per + 15) / 16) * 16;
+  return (K + ksplit - 1) / ksplit;
+}
+
+// Tile choice: features first (BN = smallest of 16/32/64/128 covering N, capped at 128), then the
+// row tile so that the grid has at least ~1 workgroup per CU (256 CUs) when the problem allows.
+template <class XL, class WL>
+inline int launch_gemm(const XL& xl, const WL& wl, const Epi& epi, int M, int N, int K, int splits, hipStream_t st) {
+  if (M <= 0 || N <= 0) return MMFT_OK;
+  auto tiles = [&](int bm, int bn) { return (long long)cdiv(M, bm) * cdiv(N, bn) * (splits > 1 ? splits : 1); };
+  if (N <= 16) {
+    if (tiles(128, 16) >= 256) launch_cfg<TileCfg<128, 16, 16, 4, 1>>(xl, wl, epi, M, N, K, splits, st);
+    else launch_cfg<TileCfg<64, 16, 16, 4, 1>>(xl, wl, epi, M, N, K, splits, st);
+  } else if (N <= 32) {
+    if (tiles(128, 32) >= 256) launch_cfg<TileCfg<128, 32, 16, 4, 1>>(xl, wl, epi, M, N, K, splits, st);
+    else launch_cfg<TileCfg<64, 32, 16, 4, 1>>(xl, wl, epi, M, N, K, splits, st);
+  } else if (N <= 64) {
+    if (tiles(128, 64) >= 256) launch_cfg<TileCfg<128, 64, 16, 2, 2>>(xl, wl, epi, M, N, K, splits, st);
+    else if (tiles(64, 64) >= 256) launch_cfg<TileCfg<64, 64, 16, 2, 2>>(xl, wl, epi, M, N, K, splits, st);
+    else launch_cfg<TileCfg<32, 64, 16, 2, 2>>(xl, wl, epi, M, N, K, splits, st);
+  } else {
+    if (tiles(128, 128) >= 256) launch_cfg<TileCfg<128, 128, 16, 2, 2>>(xl, wl, epi, M, N, K, splits, st);
+    else if (tiles(64, 128) >= 256) launch_cfg<TileCfg<64, 128, 16, 2, 2>>(xl, wl, epi, M, N, K, splits, st);
+    else launch_cfg<TileCfg<32, 128, 16, 2, 2>>(xl, wl, epi, M, N, K, splits, st);
+  }
+  return check_launch("gemm_f32");
+}
+
+// deterministic split-K combine: out[i] = (accumulate ? out[i] : 0) + sum_z slab[z][i], fixed z order
+int launch_slab_reduce(const float* slabs, int splits, long long elems, float* out, int accumulate, hipStream_t st);
+
+}  // namespace mmft

@@ -1,0 +1,236 @@
+// Netlist-graph aggregation kernels (HBM-bound gather / segmented reductions over CSR).
+// Replaces DGL graph.pull with fn.copy_src+fn.mean (reference src/model.py:186-187), the
+// degree-bucketed UDF PathConv.cell_msg_reduce (src/model.py:113-116,202-204), the activation
+// write-back and the target gather (src/model.py:206-213), and their autograd mirror.
+//
+// Layout: node features are [N][D] fp32 rows (D % 4 == 0).  One thread owns one float4 channel group
+// of one node, so the D/4 threads of a node read each neighbour row as one contiguous 16-B-per-lane
+// segment (512 B for D = 128) and no cross-lane reduction is needed; a 256-thread workgroup covers
+// 256/(D/4) nodes (8 for D = 128).  Degrees on this path are small (net in-degree 1, cell fan-in
+// ~2), so the per-thread edge loop is short; heavy-tailed out-degrees in the reverse sweep are the
+// known skew.
+#include "common.h"
+
+namespace mmft {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// node/channel-group assignment shared by all kernels here
+#define MMFT_NODE_LOOP(n, D)                                                  \
+  const int groups = (D) >> 2;                                                \
+  const long long total = (long long)(n) * groups;                            \
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; \
+       t += (long long)gridDim.x * blockDim.x)
+
+__global__ void __launch_bounds__(256) seg_softmax_sum_fwd_kernel(const float* __restrict__ h, long long ldh,
+                                                                  const int* __restrict__ indptr,
+                                                                  const int* __restrict__ indices,
+                                                                  const int* __restrict__ rows, int n, int D,
+                                                                  float* __restrict__ A, float* __restrict__ LSE,
+                                                                  long long lda) {
+  MMFT_NODE_LOOP(n, D) {
+    int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
+    int v = rows ? rows[i] : i;
+    int e0 = indptr[v], e1 = indptr[v + 1];
+    f32x4 mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
+    for (int e = e0; e < e1; ++e) {
+      f32x4 x = ld4(h + (long long)indices[e] * ldh + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float m_new = fmaxf(mx[j], x[j]);
+        float scale = expf(mx[j] - m_new);   // exp(-inf) = 0 on the first edge
+        float p = expf(x[j] - m_new);
+        s[j] = s[j] * scale + p;
+        acc[j] = acc[j] * scale + p * x[j];
+        mx[j] = m_new;
+      }
+    }
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, l = {0.f, 0.f, 0.f, 0.f};
+    if (e1 > e0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a[j] = acc[j] / s[j];
+        l[j] = mx[j] + logf(s[j]);
+      }
+    }
+    st4(A + (long long)v * lda + c, a);
+    if (LSE) st4(LSE + (long long)v * lda + c, l);
+  }
+}
+
+__global__ void __launch_bounds__(256) seg_mean_fwd_kernel(const float* __restrict__ src, long long lds,
+                                                           const int* __restrict__ indptr,
+                                                           const int* __restrict__ indices,
+                                                           const int* __restrict__ rows, int n, int D,
+                                                           float* __restrict__ out, long long ldo, int add_self,
+                                                           int relu) {
+  MMFT_NODE_LOOP(n, D) {
+    int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
+    int v = rows ? rows[i] : i;
+    int e0 = indptr[v], e1 = indptr[v + 1];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int e = e0; e < e1; ++e) acc += ld4(src + (long long)indices[e] * lds + c);
+    if (e1 > e0) acc = acc * (1.0f / (float)(e1 - e0));
+    float* o = add_self ? out + (long long)v * ldo + c : out + (long long)i * ldo + c;
+    if (add_self) acc += ld4(o);
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = acc[j] > 0.f ? acc[j] : 0.f;
+    }
+    st4(o, acc);
+  }
+}
+
+__global__ void __launch_bounds__(256) level_bwd_pull_kernel(
+    float* __restrict__ G, const float* __restrict__ h, long long ld, const int* __restrict__ rows, int n, int D,
+    const int* __restrict__ on_ptr, const int* __restrict__ on_idx, const int* __restrict__ in_net_ptr,
+    const int* __restrict__ oc_ptr, const int* __restrict__ oc_idx, const float* __restrict__ A,
+    const float* __restrict__ LSE, const float* __restrict__ DA, int relu) {
+  MMFT_NODE_LOOP(n, D) {
+    int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
+    int v = rows ? rows[i] : i;
+    long long off = (long long)v * ld + c;
+    f32x4 hv = ld4(h + off);
+    f32x4 g = ld4(G + off);
+    // net consumers: d/dh[v] of mean over the consumer's in-edges
+    for (int e = on_ptr[v]; e < on_ptr[v + 1]; ++e) {
+      int w = on_idx[e];
+      float inv = 1.0f / (float)(in_net_ptr[w + 1] - in_net_ptr[w]);
+      g += ld4(G + (long long)w * ld + c) * inv;
+    }
+    // cell consumers: d a_c / d m_jc = w_jc (1 + m_jc - a_c),  w_jc = exp(m_jc - LSE_c)
+    for (int e = oc_ptr[v]; e < oc_ptr[v + 1]; ++e) {
+      long long wo = (long long)oc_idx[e] * ld + c;
+      f32x4 da = ld4(DA + wo), a = ld4(A + wo), l = ld4(LSE + wo);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] += da[j] * expf(hv[j] - l[j]) * (1.0f + hv[j] - a[j]);
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = hv[j] > 0.f ? g[j] : 0.f;
+    }
+    st4(G + off, g);
+  }
+}
+
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restrict__ src, long long lds,
+                                                          const int* __restrict__ idx, int n, int D,
+                                                          float* __restrict__ dst, long long ldd) {
+  MMFT_NODE_LOOP(n, D) {
+    int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
+    st4(dst + (long long)i * ldd + c, ld4(src + (long long)idx[i] * lds + c));
+  }
+}
+
+__global__ void __launch_bounds__(256) scatter_add_rows_kernel(float* __restrict__ dst, long long ldd,
+                                                               const int* __restrict__ idx, int n, int D,
+                                                               const float* __restrict__ src, long long lds) {
+  MMFT_NODE_LOOP(n, D) {
+    int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
+    f32x4 v = ld4(src + (long long)i * lds + c);
+    float* q = dst + (long long)idx[i] * ldd + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(q + j, v[j]);
+  }
+}
+
+static inline int node_grid(int n, int D) { return ew_grid((long long)n * (D / 4)); }
+
+}  // namespace mmft
+
+using namespace mmft;
+
+#define CHECK_ROWS(name)                                                                              \
+  MMFT_REQUIRE(n >= 0 && D > 0 && (D % 4) == 0, name ": D must be a positive multiple of 4 (D=%d)", D)
+
+extern "C" {
+
+int mmft_seg_softmax_sum_fwd(const float* h, long long ldh, const int* in_indptr, const int* in_indices,
+                             const int* rows, int n, int D, float* A, float* LSE, long long lda, int device,
+                             void* stream) {
+  CHECK_ROWS("seg_softmax_sum_fwd");
+  MMFT_REQUIRE(h && in_indptr && A, "seg_softmax_sum_fwd: null pointer");
+  MMFT_REQUIRE(ldh >= D && lda >= D && ldh % 4 == 0 && lda % 4 == 0 && aligned16(h) && aligned16(A) &&
+                   (!LSE || aligned16(LSE)),
+               "seg_softmax_sum_fwd: rows must be 16-byte aligned");
+  if (n == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  hipLaunchKernelGGL(seg_softmax_sum_fwd_kernel, dim3(node_grid(n, D)), dim3(256), 0, (hipStream_t)stream, h, ldh,
+                     in_indptr, in_indices, rows, n, D, A, LSE, lda);
+  return check_launch("seg_softmax_sum_fwd");
+}
+
+int mmft_seg_mean_add_act_fwd(float* h, long long ldh, const int* in_indptr, const int* in_indices, const int* rows,
+                              int n, int D, int relu, int device, void* stream) {
+  CHECK_ROWS("seg_mean_add_act_fwd");
+  MMFT_REQUIRE(h && in_indptr, "seg_mean_add_act_fwd: null pointer");
+  MMFT_REQUIRE(ldh >= D && ldh % 4 == 0 && aligned16(h), "seg_mean_add_act_fwd: rows must be 16-byte aligned");
+  if (n == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  hipLaunchKernelGGL(seg_mean_fwd_kernel, dim3(node_grid(n, D)), dim3(256), 0, (hipStream_t)stream, h, ldh, in_indptr,
+                     in_indices, rows, n, D, h, ldh, 1, relu);
+  return check_launch("seg_mean_add_act_fwd");
+}
+
+int mmft_seg_mean_fwd(const float* src, long long lds, const int* in_indptr, const int* in_indices, const int* rows,
+                      int n, int D, float* out, long long ldo, int device, void* stream) {
+  CHECK_ROWS("seg_mean_fwd");
+  MMFT_REQUIRE(src && in_indptr && out, "seg_mean_fwd: null pointer");
+  MMFT_REQUIRE(lds >= D && ldo >= D && lds % 4 == 0 && ldo % 4 == 0 && aligned16(src) && aligned16(out),
+               "seg_mean_fwd: rows must be 16-byte aligned");
+  if (n == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  hipLaunchKernelGGL(seg_mean_fwd_kernel, dim3(node_grid(n, D)), dim3(256), 0, (hipStream_t)stream, src, lds,
+                     in_indptr, in_indices, rows, n, D, out, ldo, 0, 0);
+  return check_launch("seg_mean_fwd");
+}
+
+int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows, int n, int D,
+                        const int* out_net_indptr, const int* out_net_indices, const int* in_net_indptr,
+                        const int* out_cell_indptr, const int* out_cell_indices, const float* A, const float* LSE,
+                        const float* DA, int relu, int device, void* stream) {
+  CHECK_ROWS("level_bwd_pull");
+  MMFT_REQUIRE(G && h && out_net_indptr && in_net_indptr && out_cell_indptr && A && LSE && DA,
+               "level_bwd_pull: null pointer");
+  MMFT_REQUIRE(ld >= D && ld % 4 == 0 && aligned16(G) && aligned16(h) && aligned16(A) && aligned16(LSE) &&
+                   aligned16(DA),
+               "level_bwd_pull: rows must be 16-byte aligned");
+  if (n == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  hipLaunchKernelGGL(level_bwd_pull_kernel, dim3(node_grid(n, D)), dim3(256), 0, (hipStream_t)stream, G, h, ld, rows,
+                     n, D, out_net_indptr, out_net_indices, in_net_indptr, out_cell_indptr, out_cell_indices, A, LSE,
+                     DA, relu);
+  return check_launch("level_bwd_pull");
+}
+
+int mmft_gather_rows(const float* src, long long lds, const int* idx, int n, int D, float* dst, long long ldd,
+                     int device, void* stream) {
+  CHECK_ROWS("gather_rows");
+  MMFT_REQUIRE(src && dst && (idx || n == 0), "gather_rows: null pointer");
+  MMFT_REQUIRE(lds >= D && ldd >= D && lds % 4 == 0 && ldd % 4 == 0 && aligned16(src) && aligned16(dst),
+               "gather_rows: rows must be 16-byte aligned");
+  if (n == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(node_grid(n, D)), dim3(256), 0, (hipStream_t)stream, src, lds, idx, n, D,
+                     dst, ldd);
+  return check_launch("gather_rows");
+}
+
+int mmft_scatter_add_rows(float* dst, long long ldd, const int* idx, int n, int D, const float* src, long long lds,
+                          int device, void* stream) {
+  CHECK_ROWS("scatter_add_rows");
+  MMFT_REQUIRE(src && dst && (idx || n == 0), "scatter_add_rows: null pointer");
+  MMFT_REQUIRE(lds >= D && ldd >= D && lds % 4 == 0 && ldd % 4 == 0 && aligned16(src) && aligned16(dst),
+               "scatter_add_rows: rows must be 16-byte aligned");
+  if (n == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(node_grid(n, D)), dim3(256), 0, (hipStream_t)stream, dst, ldd, idx,
+                     n, D, src, lds);
+  return check_launch("scatter_add_rows");
+}
+
+}  // extern "C"

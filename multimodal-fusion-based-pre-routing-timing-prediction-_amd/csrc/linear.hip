@@ -1,0 +1,209 @@
+// Dense layers on the fp32 MFMA engine: forward, dgrad, wgrad, bias-gradient column sums, activations.
+// Replaces th.nn.Linear / LeakyReLU inside MLP (reference src/model.py:10-24).
+#include "gemm_engine.h"
+
+namespace mmft {
+
+static thread_local char g_err[512] = {0};
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---------------------------------------------------------------- split-K slab combine
+__global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, int splits, long long elems,
+                                                          float* __restrict__ out, int accumulate) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < elems; i += stride) {
+    float s = accumulate ? out[i] : 0.f;
+    for (int z = 0; z < splits; ++z) s += slabs[(long long)z * elems + i];
+    out[i] = s;
+  }
+}
+
+int launch_slab_reduce(const float* slabs, int splits, long long elems, float* out, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ew_grid(elems)), dim3(256), 0, st, slabs, splits, elems, out, accumulate);
+  return check_launch("slab_reduce");
+}
+
+// ---------------------------------------------------------------- column sums (bias gradients)
+// stage 1: each block sums a strip of rows into partial[block][cols]; stage 2 = slab_reduce (fixed order)
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ g, const int* __restrict__ idx,
+                                                             long long ld, int rows, int cols, int rows_per_block,
+                                                             float* __restrict__ partial) {
+  int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) {
+      long long rr = idx ? (long long)idx[r] : (long long)r;
+      s += g[rr * ld + c];
+    }
+    partial[(long long)blockIdx.x * cols + c] = s;
+  }
+}
+
+static inline int colsum_blocks(int rows) {
+  int nb = cdiv(rows, 64);
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  return nb;
+}
+
+__global__ void __launch_bounds__(256) act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                      float* __restrict__ dpre, long long n, int act, float slope) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float g = dy[i];
+    if (act != ACT_NONE && !(y[i] > 0.f)) g = (act == ACT_LEAKY) ? g * slope : 0.f;
+    dpre[i] = g;
+  }
+}
+
+__global__ void __launch_bounds__(256) act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n,
+                                                      int act, float slope) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float v = x[i];
+    if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
+    else if (act == ACT_LEAKY) v = v > 0.f ? v : v * slope;
+    y[i] = v;
+  }
+}
+
+}  // namespace mmft
+
+using namespace mmft;
+
+extern "C" {
+
+int mmft_version(void) { return 100; }
+const char* mmft_last_error(void) { return mmft::g_err; }
+
+int mmft_linear_fwd(const float* x, const int* xidx, long long ldx, const float* w, long long ldw, const float* bias,
+                    float* y, const int* yidx, long long ldy, int M, int N, int K, int epi_mode, int act, float slope,
+                    int device, void* stream) {
+  MMFT_REQUIRE(x && w && y, "linear_fwd: null pointer");
+  MMFT_REQUIRE(M >= 0 && N > 0 && K > 0, "linear_fwd: bad sizes M=%d N=%d K=%d", M, N, K);
+  MMFT_REQUIRE(ldx >= K && ldw >= K && ldy >= N, "linear_fwd: leading dimension smaller than row length");
+  MMFT_REQUIRE(epi_mode >= 0 && epi_mode <= 2 && act >= 0 && act <= 2, "linear_fwd: bad epilogue mode/act");
+  if (M == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  DenseMK xl{x, xidx, ldx, M, (ldx % 4 == 0) && aligned16(x)};
+  DenseMK wl{w, nullptr, ldw, N, (ldw % 4 == 0) && aligned16(w)};
+  Epi epi{y, ldy, yidx, bias, nullptr, nullptr, 0, epi_mode, act, slope, 0, (ldy % 4 == 0) && aligned16(y)};
+  return launch_gemm(xl, wl, epi, M, N, K, 1, (hipStream_t)stream);
+}
+
+int mmft_linear_dgrad(const float* g, const int* gidx, long long ldg, const float* w, long long ldw, float* dx,
+                      const int* dxidx, long long lddx, int M, int N, int K, const float* mask, const int* maskidx,
+                      long long ldmask, int epi_mode, int device, void* stream) {
+  MMFT_REQUIRE(g && w && dx, "linear_dgrad: null pointer");
+  MMFT_REQUIRE(M >= 0 && N > 0 && K > 0, "linear_dgrad: bad sizes");
+  MMFT_REQUIRE(ldg >= K && ldw >= N && lddx >= N, "linear_dgrad: leading dimension smaller than row length");
+  MMFT_REQUIRE(epi_mode == MMFT_EPI_STORE || epi_mode == MMFT_EPI_ACCUM, "linear_dgrad: bad epilogue mode");
+  MMFT_REQUIRE(!(mask && epi_mode != MMFT_EPI_STORE), "linear_dgrad: mask requires STORE");
+  if (M == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  DenseMK xl{g, gidx, ldg, M, (ldg % 4 == 0) && aligned16(g)};
+  DenseKM wl{w, nullptr, ldw, N, (ldw % 4 == 0) && aligned16(w)};
+  Epi epi{dx, lddx, dxidx, nullptr, mask, maskidx, ldmask, mask ? EPI_MASK : epi_mode, ACT_NONE, 0.f, 0,
+          (lddx % 4 == 0) && aligned16(dx)};
+  return launch_gemm(xl, wl, epi, M, N, K, 1, (hipStream_t)stream);
+}
+
+static int wgrad_splits(int rows, int out, int in) {
+  long long tiles = (long long)cdiv(out, 128) * cdiv(in, in <= 16 ? 16 : in <= 32 ? 32 : in <= 64 ? 64 : 128);
+  int want = (int)(512 / (tiles > 0 ? tiles : 1));
+  int maxs = rows / 64;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  if (want > 256) want = 256;
+  return effective_splits(rows, want);
+}
+
+long long mmft_linear_wgrad_workspace_bytes(int rows, int out, int in) {
+  int s = wgrad_splits(rows, out, in);
+  return s > 1 ? (long long)s * out * in * 4 : 0;
+}
+
+int mmft_linear_wgrad(const float* g, const int* gidx, long long ldg, const float* x, const int* xidx, long long ldx,
+                      float* dw, long long lddw, int rows, int out, int in, int accumulate, float* workspace,
+                      long long workspace_bytes, int device, void* stream) {
+  MMFT_REQUIRE(g && x && dw, "linear_wgrad: null pointer");
+  MMFT_REQUIRE(rows >= 0 && out > 0 && in > 0, "linear_wgrad: bad sizes");
+  MMFT_REQUIRE(ldg >= out && ldx >= in && lddw >= in, "linear_wgrad: leading dimension smaller than row length");
+  DeviceGuard dg(device);
+  hipStream_t st = (hipStream_t)stream;
+  int splits = wgrad_splits(rows, out, in);
+  if (rows == 0) {
+    if (!accumulate) {
+      for (int o = 0; o < out; ++o) (void)hipMemsetAsync(dw + (long long)o * lddw, 0, (size_t)in * 4, st);
+    }
+    return MMFT_OK;
+  }
+  // M := out (m-contiguous in g), N := in (n-contiguous in x), K := rows
+  DenseKM xl{g, gidx, ldg, out, (ldg % 4 == 0) && aligned16(g)};
+  DenseKM wl{x, xidx, ldx, in, (ldx % 4 == 0) && aligned16(x)};
+  if (splits <= 1 || lddw != in) {
+    // single pass straight into dw (also the path for strided dw, where slabs would not line up)
+    Epi epi{dw, lddw, nullptr, nullptr, nullptr, nullptr, 0, accumulate ? EPI_ACCUM : EPI_STORE, ACT_NONE, 0.f, 0,
+            (lddw % 4 == 0) && aligned16(dw)};
+    return launch_gemm(xl, wl, epi, out, in, rows, 1, st);
+  }
+  long long need = (long long)splits * out * in * 4;
+  MMFT_REQUIRE(workspace && workspace_bytes >= need, "linear_wgrad: workspace too small (%lld < %lld)", workspace_bytes,
+               need);
+  Epi epi{workspace, in, nullptr, nullptr, nullptr, nullptr, 0, EPI_STORE, ACT_NONE, 0.f, (long long)out * in,
+          (in % 4 == 0) && aligned16(workspace)};
+  int rc = launch_gemm(xl, wl, epi, out, in, rows, splits, st);
+  if (rc) return rc;
+  return launch_slab_reduce(workspace, splits, (long long)out * in, dw, accumulate, st);
+}
+
+long long mmft_colsum_workspace_bytes(int rows, int cols) { return (long long)colsum_blocks(rows) * cols * 4; }
+
+int mmft_colsum(const float* g, const int* idx, long long ld, int rows, int cols, float* out, int accumulate,
+                float* workspace, long long workspace_bytes, int device, void* stream) {
+  MMFT_REQUIRE(g && out, "colsum: null pointer");
+  MMFT_REQUIRE(rows >= 0 && cols > 0 && ld >= cols, "colsum: bad sizes");
+  DeviceGuard dg(device);
+  hipStream_t st = (hipStream_t)stream;
+  if (rows == 0) {
+    if (!accumulate) (void)hipMemsetAsync(out, 0, (size_t)cols * 4, st);
+    return MMFT_OK;
+  }
+  int nb = colsum_blocks(rows);
+  MMFT_REQUIRE(workspace && workspace_bytes >= (long long)nb * cols * 4, "colsum: workspace too small");
+  int rpb = cdiv(rows, nb);
+  nb = cdiv(rows, rpb);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, g, idx, ld, rows, cols, rpb, workspace);
+  int rc = check_launch("colsum_partial");
+  if (rc) return rc;
+  return launch_slab_reduce(workspace, nb, cols, out, accumulate, st);
+}
+
+int mmft_act_bwd(const float* dy, const float* y, float* dpre, long long n, int act, float slope, int device,
+                 void* stream) {
+  MMFT_REQUIRE(dy && y && dpre && n >= 0, "act_bwd: bad args");
+  if (n == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dpre, n, act, slope);
+  return check_launch("act_bwd");
+}
+
+int mmft_act_fwd(const float* x, float* y, long long n, int act, float slope, int device, void* stream) {
+  MMFT_REQUIRE(x && y && n >= 0, "act_fwd: bad args");
+  if (n == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, act, slope);
+  return check_launch("act_fwd");
+}
+
+}  // extern "C"

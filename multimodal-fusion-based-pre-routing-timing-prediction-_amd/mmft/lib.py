@@ -1,0 +1,107 @@
+"""ctypes binding of libmmft_hip.so (the C ABI declared in include/mmft.h).
+
+There is NO fallback: if the shared library is missing or an entry point fails, a RuntimeError is
+raised.  PyTorch is used only for device memory, streams and torch.distributed.
+"""
+import ctypes
+import os
+import re
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_DIR = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(PKG_DIR, 'lib', 'libmmft_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), 'include', 'mmft.h')
+
+_lib = None
+
+
+def header_decls():
+    """{name: (restype, [argtypes])} parsed from include/mmft.h - the header is the single source of truth."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    decls = {}
+    for ret, name, params in re.findall(r'\b(int|long long|const char\*)\s+(mmft_[a-z0-9_]+)\s*\(([^)]*)\)\s*;', text):
+        args = []
+        params = params.strip()
+        if params and params != 'void':
+            for prm in params.split(','):
+                prm = prm.strip()
+                if '*' in prm:
+                    args.append(ctypes.c_void_p)
+                elif prm.startswith('long long'):
+                    args.append(ctypes.c_longlong)
+                elif prm.startswith('int'):
+                    args.append(ctypes.c_int)
+                elif prm.startswith('float'):
+                    args.append(ctypes.c_float)
+                elif prm.startswith('double'):
+                    args.append(ctypes.c_double)
+                else:
+                    raise RuntimeError(f'mmft.h: cannot parse parameter "{prm}" of {name}')
+        res = {'int': ctypes.c_int, 'long long': ctypes.c_longlong, 'const char*': ctypes.c_char_p}[ret]
+        decls[name] = (res, args)
+    return decls
+
+
+def header_symbols():
+    """Names of every function declared in include/mmft.h (used by the CPU-side symbol test)."""
+    return sorted(header_decls())
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"libmmft_hip.so not found at {LIB_PATH}; build it with `python __graft_entry__.py build` "
+                f"(make -C {os.path.join(PKG_DIR, 'csrc')}). There is no CPU/eager fallback for the hot path.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in header_decls().items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def _conv(a):
+    if a is None:
+        return None
+    if torch.is_tensor(a):
+        return a.data_ptr()
+    if isinstance(a, bool):
+        return int(a)
+    return a
+
+
+def stream_args(t):
+    """(device ordinal, hipStream_t) of the current torch stream for tensor t's device."""
+    dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    return dev, torch.cuda.current_stream(dev).cuda_stream
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*[_conv(a) for a in args])
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib.mmft_last_error().decode()}")
+
+
+def query(name, *args):
+    lib = load()
+    return int(getattr(lib, name)(*[_conv(a) for a in args]))
+
+
+_workspace = {}
+
+
+def workspace(device, nbytes):
+    """Per-device scratch buffer (grown on demand, never shrunk) for split-K slabs and reductions."""
+    key = torch.device(device)
+    buf = _workspace.get(key)
+    need = max(int(nbytes), 1 << 20)
+    if buf is None or buf.numel() * 4 < need:
+        buf = torch.empty((need + 3) // 4, dtype=torch.float32, device=key)
+        _workspace[key] = buf
+    return buf

@@ -1,0 +1,180 @@
+"""Kernel-level parity: every C-ABI entry point against plain torch fp64 math on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from mmft import ops
+from mmft.detrand import det_uniform, det_ints
+from oracle import restatement as R
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5  # fp32 MFMA fmaf chains vs fp64 reference, relative to the largest output magnitude
+
+
+def T(shape, seed, dev, lo=-1.0, hi=1.0):
+    return torch.from_numpy(det_uniform(shape, seed, lo, hi)).to(dev)
+
+
+@pytest.mark.parametrize('M,N,K', [(1, 32, 1), (9, 7, 5), (300, 256, 36), (1000, 128, 256), (257, 576, 288),
+                                   (4096, 16, 144), (130, 1, 576), (64, 130, 2), (2000, 128, 1024)])
+def test_linear_fwd(dev, M, N, K):
+    x, w, b = T((M, K), 1, dev), T((N, K), 2, dev), T((N,), 3, dev)
+    ref = (x.double() @ w.double().t() + b.double())
+    y = ops.linear_fwd(x, w, b)
+    assert rel_err(y, ref) < TOL
+    y = ops.linear_fwd(x, w, b, act=ops.ACT_RELU)
+    assert rel_err(y, ref.clamp_min(0)) < TOL
+    y = ops.linear_fwd(x, w, None, act=ops.ACT_LEAKY, slope=0.1)
+    r2 = x.double() @ w.double().t()
+    assert rel_err(y, torch.where(r2 > 0, r2, 0.1 * r2)) < TOL
+
+
+def test_linear_fwd_gather_scatter_modes(dev):
+    R_, M, N, K = 500, 333, 128, 36
+    x, w, b = T((R_, K), 1, dev), T((N, K), 2, dev), T((N,), 3, dev)
+    xidx = torch.from_numpy(det_ints((M,), 4, 0, R_)).to(torch.int32).to(dev)
+    yidx = torch.randperm(R_)[:M].to(torch.int32).to(dev)
+    y0 = T((R_, N), 5, dev)
+    ref_rows = x.double()[xidx.long()] @ w.double().t() + b.double()
+    for epi, fn in ((ops.EPI_STORE, lambda old, v: v), (ops.EPI_ACCUM, lambda old, v: old + v),
+                    (ops.EPI_ADD_ACT, lambda old, v: (old + v).clamp_min(0))):
+        y = y0.clone()
+        ops.linear_fwd(x, w, b, y=y, xidx=xidx, yidx=yidx, epi=epi, act=ops.ACT_RELU if epi == ops.EPI_ADD_ACT else 0)
+        ref = y0.double().clone()
+        ref[yidx.long()] = fn(y0.double()[yidx.long()], ref_rows)
+        assert rel_err(y, ref) < TOL
+
+
+@pytest.mark.parametrize('M,N,K', [(9, 5, 7), (300, 36, 256), (1000, 256, 128), (513, 288, 576), (77, 130, 1)])
+def test_linear_dgrad(dev, M, N, K):
+    g, w = T((M, K), 1, dev), T((K, N), 2, dev)
+    ref = g.double() @ w.double()
+    assert rel_err(ops.linear_dgrad(g, w), ref) < TOL
+    mask = T((M, N), 3, dev)
+    out = ops.linear_dgrad(g, w, mask=mask)
+    assert rel_err(out, ref * (mask.double() > 0)) < TOL
+    acc = T((M, N), 4, dev)
+    out = ops.linear_dgrad(g, w, dx=acc.clone(), epi=ops.EPI_ACCUM)
+    assert rel_err(out, ref + acc.double()) < TOL
+
+
+@pytest.mark.parametrize('rows,out,inn', [(5, 7, 3), (1000, 128, 256), (40000, 256, 36), (30000, 128, 2),
+                                          (2049, 576, 288), (100000, 16, 144), (333, 1, 576)])
+def test_linear_wgrad_colsum(dev, rows, out, inn):
+    g, x = T((rows, out), 1, dev), T((rows, inn), 2, dev)
+    ref = g.double().t() @ x.double()
+    dw = ops.linear_wgrad(g, x)
+    assert rel_err(dw, ref) < TOL
+    dw2 = ops.linear_wgrad(g, x, dw=dw.clone(), accumulate=True)
+    assert rel_err(dw2, 2 * ref) < TOL
+    # bitwise reproducible (deterministic slab order)
+    assert torch.equal(ops.linear_wgrad(g, x), dw)
+    cs = ops.colsum(g)
+    assert rel_err(cs, g.double().sum(0)) < TOL
+
+
+def test_linear_wgrad_indexed(dev):
+    R_, rows, out, inn = 5000, 3000, 128, 36
+    g, x = T((R_, out), 1, dev), T((R_, inn), 2, dev)
+    idx = torch.randperm(R_)[:rows].to(torch.int32).to(dev)
+    ref = g.double()[idx.long()].t() @ x.double()[idx.long()]
+    assert rel_err(ops.linear_wgrad(g, x, gidx=idx, xidx=idx), ref) < TOL
+    assert rel_err(ops.colsum(g, idx=idx), g.double()[idx.long()].sum(0)) < TOL
+
+
+def test_act(dev):
+    x = T((1000, 7), 1, dev)
+    y = ops.act_fwd(x, ops.ACT_LEAKY, 0.1)
+    assert torch.equal(y, torch.nn.functional.leaky_relu(x, 0.1))
+    dy = T((1000, 7), 2, dev)
+    assert torch.equal(ops.act_bwd(dy, y, ops.ACT_LEAKY, 0.1), torch.where(y > 0, dy, 0.1 * dy))
+    yr = ops.act_fwd(x, ops.ACT_RELU)
+    assert torch.equal(ops.act_bwd(dy, yr, ops.ACT_RELU), torch.where(yr > 0, dy, torch.zeros_like(dy)))
+
+
+def _rand_graph(N, E, seed):
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, N, size=E)
+    dst = rng.integers(0, N, size=E)
+    dst[:50] = 7                                   # one heavy in-degree row
+    src[50:120] = 11                               # one heavy out-degree row
+    return src, dst
+
+
+@pytest.mark.parametrize('D', [16, 128])
+def test_seg_reductions(dev, D):
+    from mmft.pingraph import PinGraph
+    N, E = 700, 2500
+    src, dst = _rand_graph(N, E, 3)
+    g = PinGraph(N, {'cell': (src, dst), 'net': (src[::2], dst[::2])}).to(dev)
+    h = T((N, D), 1, dev, -3, 3)
+    rows_np = np.random.default_rng(0).permutation(N)[:400]
+    rows = torch.from_numpy(rows_np.astype(np.int32)).to(dev)
+    ip, ix = g.csr_host('in', 'cell')
+    ref = R.seg_softmax_sum(h.double().cpu(), ip, ix, rows_np)
+    A = torch.zeros_like(h); LSE = torch.zeros_like(h)
+    ops.seg_softmax_sum_fwd(h, g.csr('in', 'cell'), rows, A, LSE)
+    assert rel_err(A[rows.long()], ref) < TOL
+    # LSE against torch.logsumexp for a few rows with deg > 0
+    for v in rows_np[:40]:
+        if ip[v + 1] > ip[v]:
+            l = torch.logsumexp(h.double().cpu()[ix[ip[v]:ip[v + 1]]], 0)
+            assert rel_err(LSE[v], l) < TOL
+    ipn, ixn = g.csr_host('in', 'net')
+    refm = R.seg_mean(h.double().cpu(), ipn, ixn, rows_np)
+    assert rel_err(ops.seg_mean_fwd(h, g.csr('in', 'net'), rows), refm) < TOL
+    # in-place level update: sources must lie outside the updated rows (earlier levels), as in a sweep
+    lo = np.arange(0, N // 2)
+    ns = lo[np.random.default_rng(1).integers(0, lo.size, 900)]
+    nd = np.random.default_rng(2).integers(N // 2, N, 900)
+    g2 = PinGraph(N, {'net': (ns, nd), 'cell': ((), ())}).to(dev)
+    rows2_np = np.arange(N // 2, N)[::-1].copy()
+    rows2 = torch.from_numpy(rows2_np.astype(np.int32)).to(dev)
+    h2 = h.clone()
+    ops.seg_mean_add_act_fwd(h2, g2.csr('in', 'net'), rows2, relu=True)
+    exp = h.double().cpu().clone()
+    exp[rows2_np] = (exp[rows2_np] + R.seg_mean(h.double().cpu(), *g2.csr_host('in', 'net'), rows2_np)).clamp_min(0)
+    assert rel_err(h2, exp) < TOL
+
+
+def test_gather_scatter(dev):
+    src = T((300, 128), 1, dev)
+    idx = torch.from_numpy(det_ints((1000,), 2, 0, 300)).to(torch.int32).to(dev)
+    assert torch.equal(ops.gather_rows(src, idx), src[idx.long()])
+    dst = torch.zeros((300, 128), device=dev)
+    upd = T((1000, 128), 3, dev)
+    ops.scatter_add_rows(dst, idx, upd)
+    ref = torch.zeros((300, 128), dtype=torch.float64).index_add_(0, idx.long().cpu(), upd.double().cpu())
+    assert rel_err(dst, ref) < TOL
+
+
+def test_level_bwd_pull_matches_autograd(dev):
+    """One reverse-sweep level against torch autograd of the restated forward (fp64)."""
+    from mmft.pingraph import PinGraph
+    N, D = 300, 16
+    rng = np.random.default_rng(5)
+    # two-layer DAG: sources 0..149 feed sinks 150..299 through net and cell edges
+    ns, nd = rng.integers(0, 150, 400), rng.integers(150, 225, 400)
+    cs, cd = rng.integers(0, 150, 500), rng.integers(225, 300, 500)
+    g = PinGraph(N, {'net': (ns, nd), 'cell': (cs, cd)}).to(dev)
+    h64 = torch.from_numpy(det_uniform((N, D), 1, -2, 2)).double().requires_grad_(True)
+    net_rows, cell_rows = np.arange(150, 225), np.arange(225, 300)
+    a_net = R.seg_mean(h64, *g.csr_host('in', 'net'), net_rows)
+    a_cell = R.seg_softmax_sum(h64, *g.csr_host('in', 'cell'), cell_rows)
+    gn = torch.from_numpy(det_uniform((75, D), 2)).double()
+    gc = torch.from_numpy(det_uniform((75, D), 3)).double()
+    gt = torch.from_numpy(det_uniform((N, D), 4)).double()
+    ((a_net * gn).sum() + (a_cell * gc).sum() + (h64 * gt).sum()).backward()
+    relu_ref = torch.where(h64.detach() > 0, h64.grad, torch.zeros_like(h64.grad))[:150]
+
+    h = h64.detach().float().to(dev)
+    G = gt.float().to(dev).clone()            # target-gradient part already in G
+    G[150:225] = gn.float().to(dev)           # consumers' d/d(pre-activation)
+    A = torch.zeros_like(h); LSE = torch.zeros_like(h); DA = torch.zeros_like(h)
+    cr = torch.arange(225, 300, dtype=torch.int32, device=dev)
+    ops.seg_softmax_sum_fwd(h, g.csr('in', 'cell'), cr, A, LSE)
+    DA[225:300] = gc.float().to(dev)
+    rows = torch.arange(0, 150, dtype=torch.int32, device=dev)
+    ops.level_bwd_pull(G, h, rows, g.csr('out', 'net'), g.csr('in', 'net')[0], g.csr('out', 'cell'), A, LSE, DA, relu=True)
+    assert rel_err(G[:150], relu_ref) < 5e-5
