@@ -101,6 +101,90 @@ int mmft_gather_rows(const float* src, long long lds, const int* idx, int n, int
 int mmft_scatter_add_rows(float* dst, long long ldd, const int* idx, int n, int D, const float* src,
                           long long lds, int device, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Layout-image CNN  --  replaces nn.Conv2d / BatchNorm2d(train) / ReLU / MaxPool2d / AvgPool2d /
+ * ConvTranspose2d / F.pad / torch.cat inside DoubleConv, Down, Up, OutConv, UNet
+ * (src/Unet.py:8-119) and LayoutNet (src/model.py:216-247).
+ * Activations are NHWC fp32 ([Nimg][H][W][C], i.e. torch channels_last); conv weights are
+ * [Co][KH][KW][Ci] (the channels_last memory of an OIHW parameter).  Stride 1, 2*pad == K-1.
+ * ------------------------------------------------------------------------------------------- */
+/* y = act(conv(x, w) + bias)  (bias may be NULL: src/Unet.py:16,19 use bias=False) */
+int mmft_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int Nimg, int H, int W,
+                    int Ci, int Co, int KH, int KW, int pad, int act, float slope, int device, void* stream);
+/* dx = conv(dy, flip(w)^T); workspace holds the re-laid-out weights (>= Co*KH*KW*Ci*4 bytes) */
+int mmft_conv2d_dgrad(const float* dy, const float* w, float* dx, int Nimg, int H, int W, int Ci, int Co,
+                      int KH, int KW, int pad, float* workspace, long long workspace_bytes,
+                      int device, void* stream);
+/* dw[co][kh][kw][ci] = sum_pixels dy[p][co] * x[p+tap][ci]; deterministic split over pixels */
+long long mmft_conv2d_wgrad_workspace_bytes(int Nimg, int H, int W, int Ci, int Co, int KH, int KW);
+int mmft_conv2d_wgrad(const float* x, const float* dy, float* dw, int Nimg, int H, int W, int Ci, int Co,
+                      int KH, int KW, int pad, float* workspace, long long workspace_bytes,
+                      int device, void* stream);
+/* BatchNorm2d in TRAIN mode (the reference never calls eval()) + optional ReLU.
+ * x is [groups][rows][C]; statistics are taken per group: groups=1, rows=N*H*W is nn.BatchNorm2d;
+ * groups=N, rows=H*W gives per-sample statistics (N=1 semantics when several designs are batched),
+ * running stats then receive `groups` sequential momentum updates.  save_mean/save_invstd: [groups][C]. */
+long long mmft_bn_workspace_bytes(int groups, long long rows, int C);
+int mmft_bn_train_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float momentum, float eps, int groups, long long rows, int C,
+                      float* save_mean, float* save_invstd, int relu, float* workspace,
+                      long long workspace_bytes, int device, void* stream);
+/* g = gy * (y > 0 if relu); dgamma = sum g*xhat; dbeta = sum g;
+ * dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) with means per group */
+int mmft_bn_train_bwd(const float* gy, const float* x, const float* y, const float* gamma,
+                      const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
+                      float* dbeta, int groups, long long rows, int C, int relu, float* workspace,
+                      long long workspace_bytes, int device, void* stream);
+/* 2x2 stride-2 pooling, floor mode (MaxPool2d(2) / AvgPool2d(2)); backward recomputes the argmax
+ * (first maximum in row-major window order, as torch) */
+int mmft_pool2x2_fwd(const float* x, float* y, int Nimg, int H, int W, int C, int mode, int device, void* stream);
+int mmft_pool2x2_bwd(const float* x, const float* gy, float* dx, int Nimg, int H, int W, int C, int mode,
+                     int device, void* stream);
+/* ConvTranspose2d(k=2,s=2) = GEMM [pixels x Ci]*[Ci x 4Co] + pixel shuffle (src/Unet.py:53):
+ * shuffle:   out[n][2y+a][2x+b][co] = in[n][y][x][(a*2+b)*Co+co] + bias[co]
+ * unshuffle: out[n][y][x][(a*2+b)*Co+co] = in[n][2y+a][2x+b][co] */
+int mmft_pixel_shuffle2(const float* in, const float* bias, float* out, int Nimg, int H, int W, int Co,
+                        int device, void* stream);
+int mmft_pixel_unshuffle2(const float* in, float* out, int Nimg, int H, int W, int Co, int device, void* stream);
+/* dst[n][y+y_off][x+x_off][c_off : c_off+Cs] = src[n][y][x][:]   (torch.cat + F.pad, src/Unet.py:59-67);
+ * reverse=1 copies the same region from dst back into src (backward of cat/pad) */
+int mmft_copy_region_nhwc(float* src, int Nimg, int Hs, int Ws, int Cs, float* dst, int Hd, int Wd, int Cd,
+                          int c_off, int y_off, int x_off, int reverse, int device, void* stream);
+/* NCHW <-> NHWC with channel padding: dst[n][h][w][c] = c < C ? src[n][c][h][w] : 0, c < Cpad */
+int mmft_nchw_to_nhwc(const float* src, float* dst, int Nimg, int C, int H, int W, int Cpad, int device, void* stream);
+int mmft_nhwc_to_nchw(const float* src, float* dst, int Nimg, int C, int H, int W, int Cpad, int device, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fusion head / step glue  --  replaces `path_mask.to_dense()*feat_map` + fcn (src/train.py:500-501,
+ * src/model.py:271-272) without materialising the dense T x P map, nn.MSELoss (src/train.py:32,522)
+ * and th.optim.Adam (src/train.py:431-435,555).
+ * Masks are CSR over path ids: mask_indptr[num_paths+1], mask_cols[nnz] (column = x*map + y,
+ * src/verilog_parser_asap7.py:1332-1368); `paths[T]` selects the batch rows (duplicates allowed).
+ * ------------------------------------------------------------------------------------------- */
+/* dst[c][r] = src[r][c]   (fcn.weight [Dout][P] <-> [P][Dout]) */
+int mmft_transpose(const float* src, float* dst, int R, int C, int device, void* stream);
+/* Several designs may share one call: f is [B][P] (one feature map per design) and f_off[t] (NULL = 0)
+ * is the offset b*P of the design that batch row t belongs to.
+ * out[t][:] = bias + sum_{p in mask(paths[t])} f[f_off[t]+p] * wT[p][:]      wT is [P][Dout], Dout % 4 == 0 */
+int mmft_masked_fc_fwd(const int* mask_indptr, const int* mask_cols, const int* paths, const int* f_off, int T,
+                       const float* f, const float* wT, const float* bias, float* out, int P, int Dout,
+                       int device, void* stream);
+/* S[f_off[t]+p][:] += gout[t][:] for every p in mask(paths[t])   (S is [B*P][Dout], zeroed by the caller) */
+int mmft_masked_fc_bwd_scatter(const int* mask_indptr, const int* mask_cols, const int* paths, const int* f_off,
+                               int T, const float* gout, float* S, int P, int Dout, int device, void* stream);
+/* dw[c][p] = sum_b f[b][p]*S[b][p][c];  df[b][p] = sum_c w[c][p]*S[b][p][c]   (w, dw are [Dout][P]) */
+int mmft_masked_fc_bwd_finish(const float* S, const float* f, const float* w, float* dw, float* df,
+                              int B, int P, int Dout, int device, void* stream);
+/* loss = mean((pred-target)^2); grad[i] = 2*(pred[i]-target[i])/n   (single workgroup, n <= 2^24) */
+int mmft_mse_fwd_bwd(const float* pred, const float* target, int n, float* loss, float* grad,
+                     int device, void* stream);
+/* one Adam step over flat buffers, same operation order as torch.optim.Adam (amsgrad=False):
+ * g += wd*p; m = lerp(m, g, 1-b1); v = b2*v + (1-b2)*g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+ * gscale multiplies the gradient first (1/world_size after a sum all-reduce) */
+int mmft_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, float bias_correction1,
+                   float bias_correction2, float gscale, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

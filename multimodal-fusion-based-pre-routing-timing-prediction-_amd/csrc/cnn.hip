@@ -1,0 +1,509 @@
+// Layout-image CNN kernels: NHWC fp32 implicit-GEMM convolution (forward / dgrad / wgrad on the MFMA
+// engine), train-mode BatchNorm (+ReLU) with fp64-combined statistics, 2x2 pooling, pixel shuffle for
+// ConvTranspose2d(k2,s2), region copies for cat/pad, NCHW<->NHWC.
+// Replaces the torch modules inside the reference's src/Unet.py:8-119 and LayoutNet (src/model.py:216-247).
+#include "gemm_engine.h"
+
+namespace mmft {
+
+// ------------------------------------------------------------------ weight re-layout for dgrad
+// wd[ci][kh][kw][co] = w[co][KH-1-kh][KW-1-kw][ci]
+__global__ void __launch_bounds__(256) dgrad_weight_kernel(const float* __restrict__ w, float* __restrict__ wd, int Co,
+                                                           int KH, int KW, int Ci) {
+  int total = Co * KH * KW * Ci;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int co = i % Co;
+    int r = i / Co;
+    int kw = r % KW;
+    r /= KW;
+    int kh = r % KH;
+    int ci = r / KH;
+    wd[i] = w[(((long long)co * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * Ci + ci];
+  }
+}
+
+static int conv_fwd_launch(const float* x, const float* w, const float* bias, float* y, int Nimg, int H, int W, int Ci,
+                           int Co, int KH, int KW, int pad, int act, float slope, hipStream_t st) {
+  int M = Nimg * H * W, N = Co, K = KH * KW * Ci;
+  DenseMK wl{w, nullptr, K, N, (K % 4 == 0) && aligned16(w)};
+  Epi epi{y, Co, nullptr, bias, nullptr, nullptr, 0, EPI_STORE, act, slope, 0, (Co % 4 == 0) && aligned16(y)};
+  if (Ci % 4 == 0 && aligned16(x)) {
+    Im2colMK xl{x, H, W, Ci, KH, KW, pad, M};
+    return launch_gemm(xl, wl, epi, M, N, K, 1, st);
+  }
+  Im2colMKScalar xl{x, H, W, Ci, KH, KW, pad, M};
+  return launch_gemm(xl, wl, epi, M, N, K, 1, st);
+}
+
+// ------------------------------------------------------------------ BatchNorm (train mode)
+// stage 1: per (group, row-block) partial sums of (x - shift) and (x - shift)^2, shift = first row of
+// the group (removes the mean offset from the E[x^2]-E[x]^2 cancellation); stage 2 combines in fp64.
+constexpr int BN_ROWS_PER_BLOCK = 512;
+
+__global__ void __launch_bounds__(256) bn_partial_kernel(const float* __restrict__ x, long long rows, int C,
+                                                         int blocks_per_group, float* __restrict__ partial) {
+  __shared__ float red[2][256];
+  int grp = blockIdx.x / blocks_per_group, blk = blockIdx.x % blocks_per_group;
+  const float* xg = x + (long long)grp * rows * C;
+  long long r0 = (long long)blk * BN_ROWS_PER_BLOCK;
+  long long r1 = r0 + BN_ROWS_PER_BLOCK < rows ? r0 + BN_ROWS_PER_BLOCK : rows;
+  int lanes_per_row = C < 256 ? C : 256;           // C <= 256 assumed by host check
+  int rstep = 256 / lanes_per_row;
+  int c = threadIdx.x % lanes_per_row, rl = threadIdx.x / lanes_per_row;
+  float s = 0.f, ss = 0.f;
+  if (rl < rstep) {
+    float shift = xg[c];
+    for (long long r = r0 + rl; r < r1; r += rstep) {
+      float v = xg[r * C + c] - shift;
+      s += v;
+      ss += v * v;
+    }
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = ss;
+  __syncthreads();
+  if (threadIdx.x < lanes_per_row) {
+    float a = 0.f, b = 0.f;
+    for (int j = 0; j < rstep; ++j) {
+      a += red[0][j * lanes_per_row + threadIdx.x];
+      b += red[1][j * lanes_per_row + threadIdx.x];
+    }
+    float* q = partial + ((long long)blockIdx.x * 2) * C;
+    q[threadIdx.x] = a;
+    q[C + threadIdx.x] = b;
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ partial,
+                                                          int groups, long long rows, int C, int blocks_per_group,
+                                                          float eps, float momentum, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float* __restrict__ save_mean,
+                                                          float* __restrict__ save_invstd) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double rm = running_mean ? (double)running_mean[c] : 0.0, rv = running_var ? (double)running_var[c] : 0.0;
+  for (int g = 0; g < groups; ++g) {
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < blocks_per_group; ++b) {
+      const float* q = partial + ((long long)(g * blocks_per_group + b) * 2) * C;
+      s += (double)q[c];
+      ss += (double)q[C + c];
+    }
+    double shift = (double)x[(long long)g * rows * C + c];
+    double n = (double)rows;
+    double m_sh = s / n;
+    double var = ss / n - m_sh * m_sh;
+    if (var < 0.0) var = 0.0;
+    double mean = m_sh + shift;
+    save_mean[g * C + c] = (float)mean;
+    save_invstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    double unbiased = rows > 1 ? var * n / (n - 1.0) : var;
+    rm = (1.0 - (double)momentum) * rm + (double)momentum * mean;      // sequential updates, one per group
+    rv = (1.0 - (double)momentum) * rv + (double)momentum * unbiased;
+  }
+  if (running_mean) running_mean[c] = (float)rm;
+  if (running_var) running_var[c] = (float)rv;
+}
+
+__global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       long long rows, int C, long long total, int relu) {
+  long long per_group = rows * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    int g = (int)(i / per_group);
+    float v = (x[i] - mean[g * C + c]) * invstd[g * C + c] * gamma[c] + beta[c];
+    if (relu) v = v > 0.f ? v : 0.f;
+    y[i] = v;
+  }
+}
+
+// backward stage 1: partial sums of g and g*xhat (g = gy masked by the ReLU output)
+__global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                             const float* __restrict__ y, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, long long rows, int C,
+                                                             int blocks_per_group, int relu,
+                                                             float* __restrict__ partial) {
+  __shared__ float red[2][256];
+  int grp = blockIdx.x / blocks_per_group, blk = blockIdx.x % blocks_per_group;
+  long long base = (long long)grp * rows * C;
+  long long r0 = (long long)blk * BN_ROWS_PER_BLOCK;
+  long long r1 = r0 + BN_ROWS_PER_BLOCK < rows ? r0 + BN_ROWS_PER_BLOCK : rows;
+  int lanes_per_row = C < 256 ? C : 256;
+  int rstep = 256 / lanes_per_row;
+  int c = threadIdx.x % lanes_per_row, rl = threadIdx.x / lanes_per_row;
+  float s = 0.f, sx = 0.f;
+  if (rl < rstep) {
+    float mu = mean[grp * C + c], is = invstd[grp * C + c];
+    for (long long r = r0 + rl; r < r1; r += rstep) {
+      long long i = base + r * C + c;
+      float g = gy[i];
+      if (relu && !(y[i] > 0.f)) g = 0.f;
+      s += g;
+      sx += g * (x[i] - mu) * is;
+    }
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = sx;
+  __syncthreads();
+  if (threadIdx.x < lanes_per_row) {
+    float a = 0.f, b = 0.f;
+    for (int j = 0; j < rstep; ++j) {
+      a += red[0][j * lanes_per_row + threadIdx.x];
+      b += red[1][j * lanes_per_row + threadIdx.x];
+    }
+    float* q = partial + ((long long)blockIdx.x * 2) * C;
+    q[threadIdx.x] = a;
+    q[C + threadIdx.x] = b;
+  }
+}
+
+// stage 2: per-group means (coef[g][0..1][C]) and dgamma/dbeta summed over groups
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ partial, int groups, long long rows,
+                                                              int C, int blocks_per_group, float* __restrict__ coef,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double dg = 0.0, db = 0.0;
+  for (int g = 0; g < groups; ++g) {
+    double s = 0.0, sx = 0.0;
+    for (int b = 0; b < blocks_per_group; ++b) {
+      const float* q = partial + ((long long)(g * blocks_per_group + b) * 2) * C;
+      s += (double)q[c];
+      sx += (double)q[C + c];
+    }
+    coef[(g * 2) * C + c] = (float)(s / (double)rows);
+    coef[(g * 2 + 1) * C + c] = (float)(sx / (double)rows);
+    db += s;
+    dg += sx;
+  }
+  dgamma[c] = (float)dg;
+  dbeta[c] = (float)db;
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                           const float* __restrict__ y, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ coef, float* __restrict__ dx,
+                                                           long long rows, int C, long long total, int relu) {
+  long long per_group = rows * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    int g = (int)(i / per_group);
+    float gg = gy[i];
+    if (relu && !(y[i] > 0.f)) gg = 0.f;
+    float is = invstd[g * C + c];
+    float xh = (x[i] - mean[g * C + c]) * is;
+    dx[i] = gamma[c] * is * (gg - coef[(g * 2) * C + c] - xh * coef[(g * 2 + 1) * C + c]);
+  }
+}
+
+// ------------------------------------------------------------------ pooling
+__global__ void __launch_bounds__(256) pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int Nimg, int H,
+                                                       int W, int C, int mode) {
+  int Ho = H / 2, Wo = W / 2;
+  long long total = (long long)Nimg * Ho * Wo * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long long p = i / C;
+    int xo = (int)(p % Wo);
+    p /= Wo;
+    int yo = (int)(p % Ho);
+    int n = (int)(p / Ho);
+    const float* q = x + (((long long)n * H + 2 * yo) * W + 2 * xo) * C + c;
+    float a = q[0], b = q[C], d = q[(long long)W * C], e = q[(long long)W * C + C];
+    float r;
+    if (mode == MMFT_POOL_MAX) {
+      r = a;
+      if (b > r || b != b) r = b;      // torch: take val if (val > max) || isnan(val)
+      if (d > r || d != d) r = d;
+      if (e > r || e != e) r = e;
+    } else {
+      r = (a + b + d + e) * 0.25f;
+    }
+    y[i] = r;
+  }
+}
+
+__global__ void __launch_bounds__(256) pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                       float* __restrict__ dx, int Nimg, int H, int W, int C, int mode) {
+  int Ho = H / 2, Wo = W / 2;
+  long long total = (long long)Nimg * H * W * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long long p = i / C;
+    int xx = (int)(p % W);
+    p /= W;
+    int yy = (int)(p % H);
+    int n = (int)(p / H);
+    int yo = yy >> 1, xo = xx >> 1;
+    float r = 0.f;
+    if (yo < Ho && xo < Wo) {
+      float g = gy[(((long long)n * Ho + yo) * Wo + xo) * C + c];
+      if (mode == MMFT_POOL_MAX) {
+        const float* q = x + (((long long)n * H + 2 * yo) * W + 2 * xo) * C + c;
+        float v[4] = {q[0], q[C], q[(long long)W * C], q[(long long)W * C + C]};
+        int arg = 0;
+        float m = v[0];
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+          if (v[j] > m || v[j] != v[j]) {
+            m = v[j];
+            arg = j;
+          }
+        int me = (yy & 1) * 2 + (xx & 1);
+        r = (me == arg) ? g : 0.f;
+      } else {
+        r = g * 0.25f;
+      }
+    }
+    dx[i] = r;
+  }
+}
+
+// ------------------------------------------------------------------ pixel shuffle / region copy / layout
+__global__ void __launch_bounds__(256) pixel_shuffle_kernel(const float* __restrict__ in, const float* __restrict__ bias,
+                                                            float* __restrict__ out, int Nimg, int H, int W, int Co,
+                                                            int reverse) {
+  // forward:  out[n][2y+a][2x+b][co] = in[n][y][x][(a*2+b)*Co+co] + bias[co]
+  // reverse:  out[n][y][x][(a*2+b)*Co+co] = in[n][2y+a][2x+b][co]
+  long long total = (long long)Nimg * H * W * 4 * Co;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int co = (int)(i % Co);
+    long long p = i / Co;
+    int ab = (int)(p % 4);
+    p /= 4;
+    int x = (int)(p % W);
+    p /= W;
+    int y = (int)(p % H);
+    int n = (int)(p / H);
+    long long big = (((long long)n * 2 * H + 2 * y + (ab >> 1)) * 2 * W + 2 * x + (ab & 1)) * Co + co;
+    if (!reverse) out[big] = in[i] + (bias ? bias[co] : 0.f);
+    else out[i] = in[big];
+  }
+}
+
+__global__ void __launch_bounds__(256) copy_region_kernel(float* __restrict__ src, int Nimg, int Hs, int Ws, int Cs,
+                                                          float* __restrict__ dst, int Hd, int Wd, int Cd, int c_off,
+                                                          int y_off, int x_off, int reverse) {
+  long long total = (long long)Nimg * Hs * Ws * Cs;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % Cs);
+    long long p = i / Cs;
+    int x = (int)(p % Ws);
+    p /= Ws;
+    int y = (int)(p % Hs);
+    int n = (int)(p / Hs);
+    long long j = (((long long)n * Hd + y + y_off) * Wd + x + x_off) * Cd + c_off + c;
+    if (!reverse) dst[j] = src[i];
+    else src[i] = dst[j];
+  }
+}
+
+__global__ void __launch_bounds__(256) nchw_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int Nimg,
+                                                        int C, int H, int W, int Cpad, int to_nhwc) {
+  long long total = (long long)Nimg * H * W * Cpad;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % Cpad);
+    long long p = i / Cpad;
+    int x = (int)(p % W);
+    p /= W;
+    int y = (int)(p % H);
+    int n = (int)(p / H);
+    long long j = (((long long)n * C + c) * H + y) * W + x;
+    if (to_nhwc) dst[i] = c < C ? src[j] : 0.f;
+    else if (c < C) dst[j] = src[i];
+  }
+}
+
+static inline int bn_blocks(long long rows) { return cdiv(rows, BN_ROWS_PER_BLOCK); }
+
+}  // namespace mmft
+
+using namespace mmft;
+
+#define CONV_CHECK(name)                                                                                    \
+  MMFT_REQUIRE(Nimg > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && KH > 0 && KW > 0, name ": bad sizes");     \
+  MMFT_REQUIRE(2 * pad == KH - 1 && KH == KW, name ": only stride-1 'same' convolutions (2*pad == K-1)");   \
+  MMFT_REQUIRE((long long)Nimg* H* W < (1ll << 31) && (long long)KH * KW * Ci < (1ll << 31), name ": too large")
+
+extern "C" {
+
+int mmft_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int Nimg, int H, int W, int Ci, int Co,
+                    int KH, int KW, int pad, int act, float slope, int device, void* stream) {
+  MMFT_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
+  CONV_CHECK("conv2d_fwd");
+  DeviceGuard dg(device);
+  return conv_fwd_launch(x, w, bias, y, Nimg, H, W, Ci, Co, KH, KW, pad, act, slope, (hipStream_t)stream);
+}
+
+int mmft_conv2d_dgrad(const float* dy, const float* w, float* dx, int Nimg, int H, int W, int Ci, int Co, int KH, int KW,
+                      int pad, float* workspace, long long workspace_bytes, int device, void* stream) {
+  MMFT_REQUIRE(dy && w && dx, "conv2d_dgrad: null pointer");
+  CONV_CHECK("conv2d_dgrad");
+  long long need = (long long)Co * KH * KW * Ci * 4;
+  MMFT_REQUIRE(workspace && workspace_bytes >= need, "conv2d_dgrad: workspace too small");
+  DeviceGuard dg(device);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(dgrad_weight_kernel, dim3(ew_grid(need / 4)), dim3(256), 0, st, w, workspace, Co, KH, KW, Ci);
+  int rc = check_launch("dgrad_weight");
+  if (rc) return rc;
+  // dx[p][ci] = sum_{tap,co} dy[p+tap-pad][co] * wd[ci][tap][co]  : a forward conv with Ci<->Co swapped
+  return conv_fwd_launch(dy, workspace, nullptr, dx, Nimg, H, W, Co, Ci, KH, KW, pad, ACT_NONE, 0.f, st);
+}
+
+static int conv_wgrad_splits(int Nimg, int H, int W, int Ci, int Co, int KH, int KW) {
+  int N = KH * KW * Ci;
+  long long tiles = (long long)cdiv(Co, 128) * cdiv(N, N <= 16 ? 16 : N <= 32 ? 32 : N <= 64 ? 64 : 128);
+  long long K = (long long)Nimg * H * W;
+  int want = (int)(768 / (tiles > 0 ? tiles : 1));
+  long long maxs = K / 128;
+  if (want > maxs) want = (int)maxs;
+  if (want < 1) want = 1;
+  if (want > 512) want = 512;
+  return effective_splits((int)K, want);
+}
+
+long long mmft_conv2d_wgrad_workspace_bytes(int Nimg, int H, int W, int Ci, int Co, int KH, int KW) {
+  int s = conv_wgrad_splits(Nimg, H, W, Ci, Co, KH, KW);
+  return s > 1 ? (long long)s * Co * KH * KW * Ci * 4 : 0;
+}
+
+int mmft_conv2d_wgrad(const float* x, const float* dy, float* dw, int Nimg, int H, int W, int Ci, int Co, int KH, int KW,
+                      int pad, float* workspace, long long workspace_bytes, int device, void* stream) {
+  MMFT_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
+  CONV_CHECK("conv2d_wgrad");
+  DeviceGuard dg(device);
+  hipStream_t st = (hipStream_t)stream;
+  int M = Co, N = KH * KW * Ci, K = Nimg * H * W;
+  int splits = conv_wgrad_splits(Nimg, H, W, Ci, Co, KH, KW);
+  long long need = splits > 1 ? (long long)splits * M * N * 4 : 0;
+  MMFT_REQUIRE(splits <= 1 || (workspace && workspace_bytes >= need), "conv2d_wgrad: workspace too small");
+  DenseKM xl{dy, nullptr, Co, Co, (Co % 4 == 0) && aligned16(dy)};
+  float* outp = splits > 1 ? workspace : dw;
+  Epi epi{outp, N, nullptr, nullptr, nullptr, nullptr, 0, EPI_STORE, ACT_NONE, 0.f, (long long)M * N,
+          (N % 4 == 0) && aligned16(outp)};
+  int rc;
+  if (Ci % 4 == 0 && aligned16(x)) {
+    Im2colKM wl{x, H, W, Ci, KH, KW, pad, N};
+    rc = launch_gemm(xl, wl, epi, M, N, K, splits, st);
+  } else {
+    Im2colKMScalar wl{x, H, W, Ci, KH, KW, pad, N};
+    rc = launch_gemm(xl, wl, epi, M, N, K, splits, st);
+  }
+  if (rc || splits <= 1) return rc;
+  return launch_slab_reduce(workspace, splits, (long long)M * N, dw, 0, st);
+}
+
+long long mmft_bn_workspace_bytes(int groups, long long rows, int C) {
+  return ((long long)groups * bn_blocks(rows) * 2 * C + (long long)groups * 2 * C) * 4;
+}
+
+int mmft_bn_train_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float momentum, float eps, int groups, long long rows, int C, float* save_mean,
+                      float* save_invstd, int relu, float* workspace, long long workspace_bytes, int device,
+                      void* stream) {
+  MMFT_REQUIRE(x && y && gamma && beta && save_mean && save_invstd, "bn_train_fwd: null pointer");
+  MMFT_REQUIRE(groups > 0 && rows > 0 && C > 0 && C <= 256, "bn_train_fwd: bad sizes (C <= 256 supported)");
+  MMFT_REQUIRE(workspace && workspace_bytes >= mmft_bn_workspace_bytes(groups, rows, C), "bn_train_fwd: workspace too small");
+  DeviceGuard dg(device);
+  hipStream_t st = (hipStream_t)stream;
+  int bpg = bn_blocks(rows);
+  hipLaunchKernelGGL(bn_partial_kernel, dim3(groups * bpg), dim3(256), 0, st, x, rows, C, bpg, workspace);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, x, workspace, groups, rows, C, bpg, eps,
+                     momentum, running_mean, running_var, save_mean, save_invstd);
+  long long total = (long long)groups * rows * C;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y, gamma, beta, save_mean, save_invstd,
+                     rows, C, total, relu);
+  return check_launch("bn_train_fwd");
+}
+
+int mmft_bn_train_bwd(const float* gy, const float* x, const float* y, const float* gamma, const float* save_mean,
+                      const float* save_invstd, float* dx, float* dgamma, float* dbeta, int groups, long long rows, int C,
+                      int relu, float* workspace, long long workspace_bytes, int device, void* stream) {
+  MMFT_REQUIRE(gy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "bn_train_bwd: null pointer");
+  MMFT_REQUIRE(!relu || y, "bn_train_bwd: relu backward needs the forward output");
+  MMFT_REQUIRE(groups > 0 && rows > 0 && C > 0 && C <= 256, "bn_train_bwd: bad sizes (C <= 256 supported)");
+  MMFT_REQUIRE(workspace && workspace_bytes >= mmft_bn_workspace_bytes(groups, rows, C), "bn_train_bwd: workspace too small");
+  DeviceGuard dg(device);
+  hipStream_t st = (hipStream_t)stream;
+  int bpg = bn_blocks(rows);
+  float* coef = workspace + (long long)groups * bpg * 2 * C;
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(groups * bpg), dim3(256), 0, st, gy, x, y, save_mean, save_invstd, rows, C,
+                     bpg, relu, workspace);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, workspace, groups, rows, C, bpg, coef,
+                     dgamma, dbeta);
+  long long total = (long long)groups * rows * C;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, gy, x, y, gamma, save_mean, save_invstd,
+                     coef, dx, rows, C, total, relu);
+  return check_launch("bn_train_bwd");
+}
+
+int mmft_pool2x2_fwd(const float* x, float* y, int Nimg, int H, int W, int C, int mode, int device, void* stream) {
+  MMFT_REQUIRE(x && y && Nimg > 0 && H >= 2 && W >= 2 && C > 0 && (mode == 0 || mode == 1), "pool2x2_fwd: bad args");
+  DeviceGuard dg(device);
+  long long total = (long long)Nimg * (H / 2) * (W / 2) * C;
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, Nimg, H, W, C, mode);
+  return check_launch("pool2x2_fwd");
+}
+
+int mmft_pool2x2_bwd(const float* x, const float* gy, float* dx, int Nimg, int H, int W, int C, int mode, int device,
+                     void* stream) {
+  MMFT_REQUIRE(x && gy && dx && Nimg > 0 && H >= 2 && W >= 2 && C > 0 && (mode == 0 || mode == 1), "pool2x2_bwd: bad args");
+  DeviceGuard dg(device);
+  long long total = (long long)Nimg * H * W * C;
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, gy, dx, Nimg, H, W, C, mode);
+  return check_launch("pool2x2_bwd");
+}
+
+int mmft_pixel_shuffle2(const float* in, const float* bias, float* out, int Nimg, int H, int W, int Co, int device,
+                        void* stream) {
+  MMFT_REQUIRE(in && out && Nimg > 0 && H > 0 && W > 0 && Co > 0, "pixel_shuffle2: bad args");
+  DeviceGuard dg(device);
+  long long total = (long long)Nimg * H * W * 4 * Co;
+  hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, in, bias, out, Nimg, H,
+                     W, Co, 0);
+  return check_launch("pixel_shuffle2");
+}
+
+int mmft_pixel_unshuffle2(const float* in, float* out, int Nimg, int H, int W, int Co, int device, void* stream) {
+  MMFT_REQUIRE(in && out && Nimg > 0 && H > 0 && W > 0 && Co > 0, "pixel_unshuffle2: bad args");
+  DeviceGuard dg(device);
+  long long total = (long long)Nimg * H * W * 4 * Co;
+  hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, in, nullptr, out, Nimg,
+                     H, W, Co, 1);
+  return check_launch("pixel_unshuffle2");
+}
+
+int mmft_copy_region_nhwc(float* src, int Nimg, int Hs, int Ws, int Cs, float* dst, int Hd, int Wd, int Cd, int c_off,
+                          int y_off, int x_off, int reverse, int device, void* stream) {
+  MMFT_REQUIRE(src && dst && Nimg > 0 && Hs > 0 && Ws > 0 && Cs > 0, "copy_region_nhwc: bad args");
+  MMFT_REQUIRE(y_off >= 0 && x_off >= 0 && c_off >= 0 && Hs + y_off <= Hd && Ws + x_off <= Wd && Cs + c_off <= Cd,
+               "copy_region_nhwc: region outside destination");
+  DeviceGuard dg(device);
+  long long total = (long long)Nimg * Hs * Ws * Cs;
+  hipLaunchKernelGGL(copy_region_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, src, Nimg, Hs, Ws, Cs,
+                     dst, Hd, Wd, Cd, c_off, y_off, x_off, reverse);
+  return check_launch("copy_region_nhwc");
+}
+
+int mmft_nchw_to_nhwc(const float* src, float* dst, int Nimg, int C, int H, int W, int Cpad, int device, void* stream) {
+  MMFT_REQUIRE(src && dst && Nimg > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, "nchw_to_nhwc: bad args");
+  DeviceGuard dg(device);
+  long long total = (long long)Nimg * H * W * Cpad;
+  hipLaunchKernelGGL(nchw_nhwc_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, Nimg, C, H, W,
+                     Cpad, 1);
+  return check_launch("nchw_to_nhwc");
+}
+
+int mmft_nhwc_to_nchw(const float* src, float* dst, int Nimg, int C, int H, int W, int Cpad, int device, void* stream) {
+  MMFT_REQUIRE(src && dst && Nimg > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, "nhwc_to_nchw: bad args");
+  DeviceGuard dg(device);
+  long long total = (long long)Nimg * H * W * Cpad;
+  hipLaunchKernelGGL(nchw_nhwc_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, Nimg, C, H, W,
+                     Cpad, 0);
+  return check_launch("nhwc_to_nchw");
+}
+
+}  // extern "C"

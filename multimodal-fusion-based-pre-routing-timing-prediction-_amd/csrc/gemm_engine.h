@@ -167,6 +167,66 @@ struct Im2colKM {
   }
 };
 
+// scalar variants for channel counts that are not a multiple of 4 (first conv of UNet: Ci = 3,
+// LayoutNet: Ci = 2, dgrad of the 1-channel heads: "Ci" = 1); every element decodes its own tap
+struct Im2colMKScalar {
+  static constexpr bool KMAJOR = false;
+  const float* p;
+  int H, W, C, KH, KW, pad;
+  int rows;
+  typedef Im2colMK::Ctx Ctx;
+  __device__ __forceinline__ Ctx ctx(int m) const {
+    Im2colMK v{p, H, W, C, KH, KW, pad, rows};
+    return v.ctx(m);
+  }
+  __device__ __forceinline__ float one(const Ctx& c, int k, int kend) const {
+    if (k >= kend) return 0.f;
+    int tap = k / C;
+    int ci = k - tap * C;
+    int ky = tap / KW;
+    int kx = tap - ky * KW;
+    int yy = c.y + ky - pad, xx = c.x + kx - pad;
+    if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) return 0.f;
+    return p[((long long)(c.pix0 + yy * W + xx)) * C + ci];
+  }
+  __device__ __forceinline__ f32x4 load(const Ctx& c, int k, int kend) const {
+    f32x4 v = {one(c, k, kend), one(c, k + 1, kend), one(c, k + 2, kend), one(c, k + 3, kend)};
+    return v;
+  }
+};
+
+struct Im2colKMScalar {
+  static constexpr bool KMAJOR = true;
+  const float* p;
+  int H, W, C, KH, KW, pad;
+  int cols;
+  struct Ctx {
+    int n;
+  };
+  __device__ __forceinline__ Ctx ctx(int n) const { return Ctx{n}; }
+  __device__ __forceinline__ f32x4 load(const Ctx& c, int k, int kend) const {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (k >= kend) return v;
+    int hw = H * W;
+    int img = k / hw;
+    int rem = k - img * hw;
+    int y = rem / W;
+    int x = rem - y * W;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int n = c.n + j;
+      if (n >= cols) continue;
+      int tap = n / C;
+      int ci = n - tap * C;
+      int ky = tap / KW;
+      int yy = y + ky - pad, xx = x + (tap - ky * KW) - pad;
+      if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
+      v[j] = p[((long long)(img * hw + yy * W + xx)) * C + ci];
+    }
+    return v;
+  }
+};
+
 // ------------------------------------------------------------------------------------ epilogue
 enum { EPI_STORE = 0, EPI_ACCUM = 1, EPI_ADD_ACT = 2, EPI_MASK = 3 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };

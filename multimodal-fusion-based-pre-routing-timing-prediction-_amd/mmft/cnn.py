@@ -1,0 +1,204 @@
+"""Autograd wrappers for the layout-image CNN ops (NHWC / torch channels_last, fp32).
+
+Replaces the torch modules the reference composes in src/Unet.py:8-119 and src/model.py:216-247.
+Every op takes and returns (N,C,H,W)-shaped tensors whose memory is NHWC; inputs in another layout
+are converted once by the HIP layout kernel.
+"""
+import torch
+from . import ops
+from .ops import POOL_MAX, POOL_AVG  # noqa: F401
+
+
+class Conv2dFn(torch.autograd.Function):
+    """y = act(conv2d(x, w, stride 1, 'same' padding) + b)  (src/Unet.py:16,19,75; src/model.py:227-243)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, pad, slope):
+        act, sl = ops.act_code(slope)
+        xn = ops.to_nhwc(x)
+        y = ops.conv2d_fwd(xn, w, b, pad, act, sl)
+        ctx.pad, ctx.act, ctx.slope = pad, act, sl
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(xn, w, y if act != ops.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xn, w, y = ctx.saved_tensors
+        g = ops.to_nhwc(gy)
+        if ctx.act != ops.ACT_NONE:
+            g = ops.act_bwd(g.permute(0, 2, 3, 1), y.permute(0, 2, 3, 1), ctx.act, ctx.slope).permute(0, 3, 1, 2)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_dgrad(g, w, ctx.pad)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv2d_wgrad(xn, g, w.shape[2], w.shape[3], ctx.pad)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(ops.rows_view(g))
+        return dx, dw, db, None, None
+
+
+def conv2d(x, w, b=None, pad=0, act_slope=None):
+    return Conv2dFn.apply(x, w, b, pad, act_slope)
+
+
+class BnReluFn(torch.autograd.Function):
+    """BatchNorm2d in train mode (+ReLU)  (src/Unet.py:17-18,20-21); running stats updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, per_sample):
+        xn = ops.to_nhwc(x)
+        y, mean, invstd = ops.bn_train_fwd(xn, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps,
+                                           relu, per_sample)
+        ctx.relu = relu
+        ctx.save_for_backward(xn, y, gamma, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xn, y, gamma, mean, invstd = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.bn_train_bwd(ops.to_nhwc(gy), xn, y, gamma.detach(), mean, invstd, ctx.relu)
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def bn_relu(x, bn, relu=True, per_sample=False):
+    """`bn` is an nn.BatchNorm2d holding the parameters/buffers; always batch statistics."""
+    if bn.momentum is None or not bn.affine:
+        raise NotImplementedError('BatchNorm2d without momentum/affine is not on the reference path')
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += x.shape[0] if per_sample else 1
+    return BnReluFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu, per_sample)
+
+
+class Pool2x2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode):
+        xn = ops.to_nhwc(x)
+        ctx.mode = mode
+        ctx.save_for_backward(xn)
+        return ops.pool2x2_fwd(xn, mode)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (xn,) = ctx.saved_tensors
+        return ops.pool2x2_bwd(xn, ops.to_nhwc(gy), ctx.mode), None
+
+
+def pool2x2(x, mode):
+    return Pool2x2Fn.apply(x, mode)
+
+
+def _flat(t):
+    """contiguous-memory view of a contiguous or channels_last tensor (None otherwise)."""
+    if t.is_contiguous():
+        return t
+    if t.dim() == 4 and ops.is_nhwc(t):
+        return t.permute(0, 2, 3, 1)
+    return None
+
+
+class ActFn(torch.autograd.Function):
+    """Standalone ReLU / LeakyReLU (OutConv's ReLU after the pool, src/Unet.py:74-78)."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        act, sl = ops.act_code(slope)
+        xc = x if _flat(x) is not None else x.contiguous()
+        y = torch.empty_like(xc)
+        ops.act_fwd(_flat(xc), act, sl, out=_flat(y))
+        ctx.act, ctx.slope = act, sl
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        if y.is_contiguous():
+            g = gy if gy.is_contiguous() else gy.contiguous()
+            return ops.act_bwd(g, y, ctx.act, ctx.slope), None
+        g = ops.to_nhwc(gy)
+        return ops.act_bwd(_flat(g), _flat(y), ctx.act, ctx.slope).permute(0, 3, 1, 2), None
+
+
+def relu(x):
+    return ActFn.apply(x, 0.0)
+
+
+def _wr(w):
+    """ConvTranspose2d weight (Ci,Co,2,2) -> [(a,b,co)][ci] matrix (free for parameters stored in that order)."""
+    v = w.detach().permute(2, 3, 1, 0)
+    v = v if v.is_contiguous() else v.contiguous()
+    return v.reshape(-1, w.shape[0])
+
+
+class ConvT2x2Fn(torch.autograd.Function):
+    """ConvTranspose2d(k=2, s=2) with bias  (src/Unet.py:53) = GEMM [pixels x Ci][Ci x 4Co] + pixel shuffle."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xn = ops.to_nhwc(x)
+        N, Ci, H, W = xn.shape
+        Co = w.shape[1]
+        t = ops.linear_fwd(ops.rows_view(xn), _wr(w), None)
+        y = ops.pixel_shuffle2(t, b, N, H, W, Co)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(xn, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xn, w = ctx.saved_tensors
+        g = ops.to_nhwc(gy)
+        N, Ci, H, W = xn.shape
+        Co = w.shape[1]
+        gu = ops.pixel_unshuffle2(g)                       # [pixels, 4Co]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear_dgrad(gu, _wr(w)).reshape(N, H, W, Ci).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            dwr = ops.linear_wgrad(gu, ops.rows_view(xn))  # [(a,b,co)][ci]
+            dw = dwr.reshape(2, 2, Co, Ci).permute(3, 2, 0, 1)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(ops.rows_view(g))
+        return dx, dw, db
+
+
+def conv_transpose2x2(x, w, b):
+    if tuple(w.shape[2:]) != (2, 2):
+        raise NotImplementedError('only ConvTranspose2d(kernel_size=2, stride=2) is on the reference path')
+    return ConvT2x2Fn.apply(x, w, b)
+
+
+class CatPadFn(torch.autograd.Function):
+    """torch.cat([x2, F.pad(x1, centre)], dim=1)  (src/Unet.py:59-67)."""
+
+    @staticmethod
+    def forward(ctx, x2, x1):
+        a, b = ops.to_nhwc(x2), ops.to_nhwc(x1)
+        N, C2, H, W = a.shape
+        C1, h1, w1 = b.shape[1], b.shape[2], b.shape[3]
+        dy, dx = H - h1, W - w1
+        if dy < 0 or dx < 0:
+            raise NotImplementedError('Up: the upsampled map is larger than the skip connection')
+        out = ops.empty_nhwc(N, C2 + C1, H, W, a.device)
+        if dy or dx:
+            out.zero_()
+        ops.copy_region(a, out, 0, 0, 0)
+        ops.copy_region(b, out, C2, dy // 2, dx // 2)
+        ctx.geom = (C2, C1, h1, w1, dy // 2, dx // 2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        C2, C1, h1, w1, yo, xo = ctx.geom
+        g = ops.to_nhwc(g)
+        N, _, H, W = g.shape
+        g2 = ops.empty_nhwc(N, C2, H, W, g.device)
+        g1 = ops.empty_nhwc(N, C1, h1, w1, g.device)
+        ops.copy_region(g2, g, 0, 0, 0, reverse=True)
+        ops.copy_region(g1, g, C2, yo, xo, reverse=True)
+        return g2, g1
+
+
+def cat_pad(x2, x1):
+    return CatPadFn.apply(x2, x1)

@@ -1,0 +1,47 @@
+"""Autograd wrappers over the HIP kernels for the dense layers (MLP, fcn, fusion head).
+
+Backward runs on PyTorch's autograd worker thread: every call is stateless, device and stream are
+taken from the tensors / current stream at call time, and `backward(retain_graph=True)`
+(reference src/train.py:553) is tolerated because nothing is freed or mutated in backward.
+"""
+import torch
+from . import ops
+
+
+class LinearActFn(torch.autograd.Function):
+    """y = act(x @ w.T + b) with act in {none, ReLU, LeakyReLU(slope)}  (src/model.py:10-24)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, slope):
+        act, sl = ops.act_code(slope)
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        wc = w if w.is_contiguous() else w.contiguous()
+        y = ops.linear_fwd(x2, wc, b, act=act, slope=sl)
+        ctx.act, ctx.slope, ctx.xshape = act, sl, x.shape
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x2, wc, y)
+        return y.reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w, y = ctx.saved_tensors
+        g = gy.reshape(-1, gy.shape[-1])
+        if not g.is_contiguous():
+            g = g.contiguous()
+        if ctx.act != ops.ACT_NONE:
+            g = ops.act_bwd(g, y, ctx.act, ctx.slope)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear_dgrad(g, w).reshape(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dw = ops.linear_wgrad(g, x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(g)
+        return dx, dw, db, None
+
+
+def linear_act(x, w, b=None, slope=None):
+    """act(x @ w.T + b); slope None = no activation, 0 = ReLU, >0 = LeakyReLU(slope)."""
+    return LinearActFn.apply(x, w, b, slope)

@@ -24,7 +24,7 @@ def _chk(t, name, dtype=torch.float32):
 
 def _rows2d(t, name):
     _chk(t, name)
-    if t.dim() != 2 or t.stride(1) != 1:
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
         raise ValueError(f'{name}: expected a 2-D tensor with unit inner stride, got shape {tuple(t.shape)} '
                          f'strides {t.stride()}')
     return t
@@ -241,3 +241,190 @@ def scatter_add_rows(dst, idx, src):
     dev, st = lib.stream_args(dst)
     lib.call('mmft_scatter_add_rows', dst, dst.stride(0), idx, idx.numel(), dst.shape[1], src, src.stride(0), dev, st)
     return dst
+
+
+# ------------------------------------------------------------------------------------------ CNN (NHWC)
+def is_nhwc(t):
+    return t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous()
+
+
+def _nhwc(t, name):
+    _chk(t, name)
+    if not is_nhwc(t):
+        raise ValueError(f'{name}: expected an (N,C,H,W) tensor in channels_last memory format')
+    return t
+
+
+def empty_nhwc(N, C, H, W, device):
+    return torch.empty((N, H, W, C), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+
+
+def to_nhwc(x):
+    """(N,C,H,W) any layout -> channels_last memory, through the HIP layout kernel for NCHW-contiguous input."""
+    _chk(x, 'x')
+    if is_nhwc(x):
+        return x
+    N, C, H, W = x.shape
+    if not x.is_contiguous():
+        x = x.contiguous()
+    out = empty_nhwc(N, C, H, W, x.device)
+    dev, st = lib.stream_args(x)
+    lib.call('mmft_nchw_to_nhwc', x, out, N, C, H, W, C, dev, st)
+    return out
+
+
+def to_nchw(x):
+    """channels_last -> NCHW-contiguous copy."""
+    _nhwc(x, 'x')
+    N, C, H, W = x.shape
+    out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+    dev, st = lib.stream_args(x)
+    lib.call('mmft_nhwc_to_nchw', x, out, N, C, H, W, C, dev, st)
+    return out
+
+
+def _w_ohwi(w):
+    """OIHW parameter -> [Co][KH][KW][Ci] memory (free when the parameter is stored channels_last)."""
+    _chk(w, 'weight')
+    v = w.detach().permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def conv2d_fwd(x, w, bias, pad, act=ACT_NONE, slope=0.0):
+    _nhwc(x, 'x')
+    N, Ci, H, W = x.shape
+    Co, Ci2, KH, KW = w.shape
+    if Ci2 != Ci:
+        raise ValueError(f'conv2d: input has {Ci} channels, weight expects {Ci2}')
+    wk = _w_ohwi(w)
+    if bias is not None:
+        _chk(bias, 'bias')
+        if bias.numel() != Co:
+            raise ValueError('conv2d: bias size')
+    y = empty_nhwc(N, Co, H, W, x.device)
+    dev, st = lib.stream_args(x)
+    lib.call('mmft_conv2d_fwd', x, wk, bias, y, N, H, W, Ci, Co, KH, KW, pad, act, float(slope), dev, st)
+    return y
+
+
+def conv2d_dgrad(gy, w, pad):
+    _nhwc(gy, 'gy')
+    N, Co, H, W = gy.shape
+    Co2, Ci, KH, KW = w.shape
+    if Co2 != Co:
+        raise ValueError('conv2d_dgrad: channel mismatch')
+    wk = _w_ohwi(w)
+    dx = empty_nhwc(N, Ci, H, W, gy.device)
+    ws = lib.workspace(gy.device, wk.numel() * 4)
+    dev, st = lib.stream_args(gy)
+    lib.call('mmft_conv2d_dgrad', gy, wk, dx, N, H, W, Ci, Co, KH, KW, pad, ws, ws.numel() * 4, dev, st)
+    return dx
+
+
+def conv2d_wgrad(x, gy, KH, KW, pad):
+    """returns dw as an OIHW-shaped view over [Co][KH][KW][Ci] memory."""
+    _nhwc(x, 'x'); _nhwc(gy, 'gy')
+    N, Ci, H, W = x.shape
+    Co = gy.shape[1]
+    if gy.shape[0] != N or gy.shape[2:] != x.shape[2:]:
+        raise ValueError('conv2d_wgrad: shape mismatch')
+    dw = torch.empty((Co, KH, KW, Ci), dtype=torch.float32, device=x.device)
+    need = lib.query('mmft_conv2d_wgrad_workspace_bytes', N, H, W, Ci, Co, KH, KW)
+    ws = lib.workspace(x.device, need)
+    dev, st = lib.stream_args(x)
+    lib.call('mmft_conv2d_wgrad', x, gy, dw, N, H, W, Ci, Co, KH, KW, pad, ws, ws.numel() * 4, dev, st)
+    return dw.permute(0, 3, 1, 2)
+
+
+def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu, per_sample=False):
+    _nhwc(x, 'x')
+    N, C, H, W = x.shape
+    for t, nm in ((gamma, 'gamma'), (beta, 'beta')):
+        _chk(t, nm)
+        if t.numel() != C or not t.is_contiguous():
+            raise ValueError(f'bn: {nm} shape')
+    groups, rows = (N, H * W) if per_sample else (1, N * H * W)
+    y = empty_nhwc(N, C, H, W, x.device)
+    mean = torch.empty((groups, C), dtype=torch.float32, device=x.device)
+    invstd = torch.empty((groups, C), dtype=torch.float32, device=x.device)
+    ws = lib.workspace(x.device, lib.query('mmft_bn_workspace_bytes', groups, rows, C))
+    dev, st = lib.stream_args(x)
+    lib.call('mmft_bn_train_fwd', x, y, gamma, beta, running_mean, running_var, float(momentum), float(eps), groups,
+             rows, C, mean, invstd, int(relu), ws, ws.numel() * 4, dev, st)
+    return y, mean, invstd
+
+
+def bn_train_bwd(gy, x, y, gamma, mean, invstd, relu):
+    _nhwc(gy, 'gy'); _nhwc(x, 'x')
+    N, C, H, W = x.shape
+    groups = mean.shape[0]
+    rows = N * H * W // groups
+    dx = empty_nhwc(N, C, H, W, x.device)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = lib.workspace(x.device, lib.query('mmft_bn_workspace_bytes', groups, rows, C))
+    dev, st = lib.stream_args(x)
+    lib.call('mmft_bn_train_bwd', gy, x, y, gamma, mean, invstd, dx, dgamma, dbeta, groups, rows, C, int(relu), ws,
+             ws.numel() * 4, dev, st)
+    return dx, dgamma, dbeta
+
+
+def pool2x2_fwd(x, mode):
+    _nhwc(x, 'x')
+    N, C, H, W = x.shape
+    if H < 2 or W < 2:
+        raise ValueError('pool2x2: input smaller than the window')
+    y = empty_nhwc(N, C, H // 2, W // 2, x.device)
+    dev, st = lib.stream_args(x)
+    lib.call('mmft_pool2x2_fwd', x, y, N, H, W, C, mode, dev, st)
+    return y
+
+
+def pool2x2_bwd(x, gy, mode):
+    _nhwc(x, 'x'); _nhwc(gy, 'gy')
+    N, C, H, W = x.shape
+    if tuple(gy.shape) != (N, C, H // 2, W // 2):
+        raise ValueError('pool2x2_bwd: gradient shape')
+    dx = empty_nhwc(N, C, H, W, x.device)
+    dev, st = lib.stream_args(x)
+    lib.call('mmft_pool2x2_bwd', x, gy, dx, N, H, W, C, mode, dev, st)
+    return dx
+
+
+def pixel_shuffle2(t, bias, N, H, W, Co):
+    """t: [N*H*W, 4*Co] rows -> (N,Co,2H,2W) channels_last, + bias[co]."""
+    _rows2d(t, 't')
+    if t.shape != (N * H * W, 4 * Co) or not t.is_contiguous():
+        raise ValueError('pixel_shuffle2: bad input shape')
+    out = empty_nhwc(N, Co, 2 * H, 2 * W, t.device)
+    dev, st = lib.stream_args(t)
+    lib.call('mmft_pixel_shuffle2', t, bias, out, N, H, W, Co, dev, st)
+    return out
+
+
+def pixel_unshuffle2(g):
+    """(N,Co,2H,2W) channels_last -> [N*H*W, 4*Co] rows."""
+    _nhwc(g, 'g')
+    N, Co, H2, W2 = g.shape
+    H, W = H2 // 2, W2 // 2
+    out = torch.empty((N * H * W, 4 * Co), dtype=torch.float32, device=g.device)
+    dev, st = lib.stream_args(g)
+    lib.call('mmft_pixel_unshuffle2', g, out, N, H, W, Co, dev, st)
+    return out
+
+
+def copy_region(src, dst, c_off, y_off, x_off, reverse=False):
+    """dst[:, c_off:c_off+Cs, y_off:y_off+Hs, x_off:x_off+Ws] = src  (or the reverse copy)."""
+    _nhwc(src, 'src'); _nhwc(dst, 'dst')
+    N, Cs, Hs, Ws = src.shape
+    Nd, Cd, Hd, Wd = dst.shape
+    if N != Nd or c_off + Cs > Cd or y_off + Hs > Hd or x_off + Ws > Wd or min(c_off, y_off, x_off) < 0:
+        raise ValueError('copy_region: region outside destination')
+    dev, st = lib.stream_args(src)
+    lib.call('mmft_copy_region_nhwc', src, N, Hs, Ws, Cs, dst, Hd, Wd, Cd, c_off, y_off, x_off, int(reverse), dev, st)
+    return src if reverse else dst
+
+
+def rows_view(x):
+    """(N,C,H,W) channels_last -> [N*H*W, C] row-major view."""
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])

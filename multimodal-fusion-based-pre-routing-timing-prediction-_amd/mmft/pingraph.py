@@ -148,6 +148,9 @@ class PinGraph:
         `cur_nodes` / `targets` arrive as python int lists on every call
         (src/train.py:491-503); re-uploading them per call is what the cache avoids.
         """
+        if torch.is_tensor(nodes) and nodes.dtype == torch.int32 and nodes.device == self.device:
+            # already resident (the harness uploads a step's targets in one copy): caller guarantees the range
+            return nodes if nodes.is_contiguous() else nodes.contiguous()
         key = (tag, level_id)
         hit = self._level_cache.get(key)
         if hit is not None:

@@ -1,0 +1,209 @@
+"""Levelized netlist sweep on the GPU: forward per level, deterministic reverse sweep, batched weight grads.
+
+Mirrors PathConv.forward (reference src/model.py:158-213) one call per topological level, as the
+reference loops demand (src/train.py:490-511), but keeps ONE set of [N, .] buffers updated in place
+instead of DGL's out-of-place frame update per pull:
+
+    h   [N, D]   node embeddings (= graph.ndata['h'], rows written once per sweep)
+    A   [N, D]   softmax-weighted fan-in sums of cell-level nodes      LSE [N, D]  their log-sum-exp
+    HS  [N, Hd]  hidden activations of the *_self MLPs                 HN  [N, Hd] of fc_cell_neigh
+    G   [N, D]   d loss / d pre-activation (reverse sweep)             DA  [N, D]  d loss / d A
+
+Autograd sees a chain of LevelFn nodes linked by a 1-element token, so the engine runs the levels'
+backward in strictly decreasing level order.  Each backward does: scatter the target gradients,
+one pull kernel over the level's OUT-edges (no atomics, bitwise reproducible), and for cell levels the
+two small GEMMs that turn G into DA.  Weight gradients are NOT computed per level: the level-0 node
+(last to run) computes all of them in batched GEMMs over every node of the sweep.
+"""
+import torch
+from . import ops
+
+_MLP_KEYS = ('fc_cell_self', 'fc_net_self', 'fc_cell_neigh')
+
+
+class SweepState:
+    def __init__(self, graph, conv):
+        self.graph = graph
+        h = graph.ndata['h']
+        if not (torch.is_tensor(h) and h.is_cuda and h.dtype == torch.float32 and h.dim() == 2 and h.is_contiguous()):
+            raise RuntimeError("PathConv: graph.ndata['h'] must be a contiguous float32 CUDA tensor [N, out_dim] "
+                               "(the HIP sweep has no CPU fallback)")
+        if h.shape[0] != graph.number_of_nodes() or h.shape[1] != conv.out_feat_dim:
+            raise ValueError(f"graph.ndata['h'] has shape {tuple(h.shape)}, expected "
+                             f"({graph.number_of_nodes()}, {conv.out_feat_dim})")
+        self.h = h
+        self.N, self.D = h.shape
+        self.Hd = conv.fc_cell_self.layers[0].weight.shape[0]
+        self.relu = conv.activation is not None
+        self.cell_feat = _feat(graph, 'cell_feat', conv.cell_feat_dim)
+        self.net_feat = _feat(graph, 'net_feat', conv.net_feat_dim)
+        self.params = [p for k in _MLP_KEYS for p in _mlp2_params(getattr(conv, k))]
+        self.need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.params)
+        bufs = graph.__dict__.setdefault('_sweep_bufs', {})
+        key = (self.N, self.D, self.Hd, h.device)
+        if bufs.get('key') != key:
+            bufs.clear()
+            bufs['key'] = key
+        self._bufs = bufs
+        self.A = self._buf('A', self.D)
+        self.LSE = self._buf('LSE', self.D)
+        self.HS = self._buf('HS', self.Hd)
+        self.HN = self._buf('HN', self.Hd)
+        self.G = self.DA = None
+        self.levels = []            # (level_id, rows) in forward order
+        self.token = None
+        self.next_level = 0
+        self.bwd_active = False
+
+    def _buf(self, name, width):
+        b = self._bufs.get(name)
+        if b is None:
+            b = torch.empty((self.N, width), dtype=torch.float32, device=self.h.device)
+            self._bufs[name] = b
+        return b
+
+    def begin_backward(self):
+        if not self.bwd_active:
+            if self.G is None:
+                self.G = self._buf('G', self.D)
+                self.DA = self._buf('DA', self.D)
+            self.G.zero_()
+            self.DA.zero_()
+            self.bwd_active = True
+
+
+def _feat(graph, name, width):
+    t = graph.ndata[name]
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2):
+        raise RuntimeError(f"graph.ndata['{name}'] must be a float32 CUDA tensor")
+    if t.shape[1] != width:
+        raise ValueError(f"graph.ndata['{name}'] has {t.shape[1]} columns, the model expects {width}")
+    if t.stride(1) != 1:
+        t = t.contiguous()
+        graph.ndata[name] = t
+    return t
+
+
+def _mlp2_params(mlp):
+    lin = [m for m in mlp.layers if isinstance(m, torch.nn.Linear)]
+    if len(lin) != 2 or len(mlp.layers) != 3 or getattr(mlp, 'negative_slope', 0) != 0:
+        raise NotImplementedError('PathConv level kernels expect Linear-LeakyReLU(0)-Linear MLPs (src/model.py:48-51)')
+    return [lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias]
+
+
+def _w(p):
+    d = p.detach()
+    return d if d.is_contiguous() else d.contiguous()
+
+
+class LevelFn(torch.autograd.Function):
+    """One PathConv.forward call. Inputs: chain token (+ the 12 MLP parameters at level 0)."""
+
+    @staticmethod
+    def forward(ctx, token, state, level_id, rows, tix, *params):
+        st, g = state, state.graph
+        P = [_w(p) for p in st.params]
+        (w1c, b1c, w2c, b2c, w1n, b1n, w2n, b2n, w1g, b1g, w2g, b2g) = P
+        n = rows.numel()
+        act = ops.ACT_RELU if st.relu else ops.ACT_NONE
+        if n:
+            if level_id % 2 == 1:                                                     # net level :186-187
+                ops.linear_fwd(st.net_feat, w1n, b1n, y=st.HS, xidx=rows, yidx=rows, act=ops.ACT_RELU)
+                ops.linear_fwd(st.HS, w2n, b2n, y=st.h, xidx=rows, yidx=rows)
+                ops.seg_mean_add_act_fwd(st.h, g.csr('in', 'net'), rows, relu=st.relu)
+            elif level_id == 0:                                                       # :148-153
+                ops.linear_fwd(st.cell_feat, w1c, b1c, y=st.HS, xidx=rows, yidx=rows, act=ops.ACT_RELU)
+                ops.linear_fwd(st.HS, w2c, b2c, y=st.h, xidx=rows, yidx=rows, act=act)
+            else:                                                                     # cell level :113-116,138-146
+                ops.seg_softmax_sum_fwd(st.h, g.csr('in', 'cell'), rows, st.A, st.LSE)
+                ops.linear_fwd(st.cell_feat, w1c, b1c, y=st.HS, xidx=rows, yidx=rows, act=ops.ACT_RELU)
+                ops.linear_fwd(st.HS, w2c, b2c, y=st.h, xidx=rows, yidx=rows)
+                ops.linear_fwd(st.A, w1g, b1g, y=st.HN, xidx=rows, yidx=rows, act=ops.ACT_RELU)
+                ops.linear_fwd(st.HN, w2g, b2g, y=st.h, xidx=rows, yidx=rows, epi=ops.EPI_ADD_ACT, act=act)
+        st.levels.append((level_id, rows))
+        out = ops.gather_rows(st.h, tix) if tix.numel() else st.h.new_zeros((0, st.D))       # :213
+        ctx.state, ctx.level_id, ctx.rows, ctx.tix = st, level_id, rows, tix
+        ctx.nparams = len(params)
+        new_token = st.h.new_zeros(1)
+        return new_token, out
+
+    @staticmethod
+    def backward(ctx, gtoken, gout):
+        st, g, level_id, rows = ctx.state, ctx.state.graph, ctx.level_id, ctx.rows
+        st.begin_backward()
+        if ctx.tix.numel() and gout is not None:
+            go = gout if gout.is_contiguous() else gout.contiguous()
+            ops.scatter_add_rows(st.G, ctx.tix, go)
+        P = [_w(p) for p in st.params]
+        (w1c, b1c, w2c, b2c, w1n, b1n, w2n, b2n, w1g, b1g, w2g, b2g) = P
+        if rows.numel():
+            ops.level_bwd_pull(st.G, st.h, rows, g.csr('out', 'net'), g.csr('in', 'net')[0], g.csr('out', 'cell'),
+                               st.A, st.LSE, st.DA, relu=st.relu)
+            if level_id % 2 == 0 and level_id > 0:
+                dhn = ops.linear_dgrad(st.G, w2g, gidx=rows, mask=st.HN, maskidx=rows)
+                ops.linear_dgrad(dhn, w1g, dx=st.DA, dxidx=rows)
+        grads = [None] * ctx.nparams
+        if level_id == 0:
+            if ctx.nparams:
+                grads = _batched_param_grads(st, P)
+            st.bwd_active = False
+        return (torch.zeros_like(gtoken) if ctx.needs_input_grad[0] else None, None, None, None, None, *grads)
+
+
+def _cat_rows(st, pred):
+    sel = [r for (l, r) in st.levels if pred(l) and r.numel()]
+    if not sel:
+        return None
+    return sel[0] if len(sel) == 1 else torch.cat(sel)
+
+
+def _mlp_grads(st, G, gidx, H, X, xidx, w2):
+    """Gradients of one Linear-ReLU-Linear MLP over the rows `gidx`: (dW1, db1, dW2, db2)."""
+    dW2 = ops.linear_wgrad(G, H, gidx=gidx, xidx=gidx)
+    db2 = ops.colsum(G, idx=gidx)
+    dH = ops.linear_dgrad(G, w2, gidx=gidx, mask=H, maskidx=gidx)
+    dW1 = ops.linear_wgrad(dH, X, xidx=xidx)
+    db1 = ops.colsum(dH)
+    return [dW1, db1, dW2, db2]
+
+
+def _batched_param_grads(st, P):
+    (w1c, b1c, w2c, b2c, w1n, b1n, w2n, b2n, w1g, b1g, w2g, b2g) = P
+    rc = _cat_rows(st, lambda l: l % 2 == 0)
+    rn = _cat_rows(st, lambda l: l % 2 == 1)
+    rc2 = _cat_rows(st, lambda l: l % 2 == 0 and l > 0)
+    zeros = lambda ps: [torch.zeros_like(p) for p in ps]
+    gc = _mlp_grads(st, st.G, rc, st.HS, st.cell_feat, rc, w2c) if rc is not None else zeros(P[0:4])
+    gn = _mlp_grads(st, st.G, rn, st.HS, st.net_feat, rn, w2n) if rn is not None else zeros(P[4:8])
+    gg = _mlp_grads(st, st.G, rc2, st.HN, st.A, rc2, w2g) if rc2 is not None else zeros(P[8:12])
+    return gc + gn + gg
+
+
+def level_forward(conv, graph, cur_nodes, targets, level_id):
+    """Body of PathConv.forward for the default (non-attention) branch."""
+    if level_id == 0 or graph._sweep is None:
+        if level_id != 0:
+            raise RuntimeError('PathConv: a sweep must start at level 0 (src/train.py:489-490)')
+        graph._sweep = SweepState(graph, conv)
+    st = graph._sweep
+    if graph.ndata['h'] is not st.h:
+        raise RuntimeError("graph.ndata['h'] was replaced in the middle of a sweep; restart from level 0")
+    if level_id != st.next_level:
+        raise RuntimeError(f'PathConv: levels must arrive in increasing order (got {level_id}, expected {st.next_level})')
+    st.next_level = level_id + 1
+    rows = graph.level_rows(level_id, cur_nodes, 'nodes')
+    tix = graph.level_rows(level_id, targets, 'targets')
+    if level_id == 0:
+        token = st.h.new_zeros(1)
+        if st.need_grad:
+            st.token, out = LevelFn.apply(token, st, level_id, rows, tix, *st.params)
+        else:
+            with torch.no_grad():
+                st.token, out = LevelFn.apply(token, st, level_id, rows, tix)
+    else:
+        if st.need_grad:
+            st.token, out = LevelFn.apply(st.token, st, level_id, rows, tix)
+        else:
+            with torch.no_grad():
+                st.token, out = LevelFn.apply(st.token, st, level_id, rows, tix)
+    return out

@@ -1,0 +1,148 @@
+"""Reference-shaped train step on the HIP path (the caller side of the hot path, src/train.py:461-562).
+
+`build_models` follows init_model (src/train.py:34-93) with the snapshot defects D1/D2 of SURVEY.md §0.1
+resolved the only way model.py allows: PathModel(gnn, None, fcn, None, None, mlp_fuse) and
+mlp_fuse = MLP(D_gnn + D_cnn + 32, 2*(...), nlabels).
+
+`TrainStep` runs one mini-batch exactly as the reference loop does - per level `model(graph, nodes, eids,
+targets, level_id, level_id_th, path_map)` through the drop-in modules - for one design or for several
+designs merged block-diagonally (same-index levels concatenated, per-image BatchNorm statistics), then MSE
+on arrival time, backward and Adam.  Under torch.distributed the flat gradient buffer is all-reduced
+(RCCL over xGMI) before the fused Adam kernel.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .pingraph import PinGraph
+from .fusion import PathMasks, MaskedPathMap, FlatAdam, mse_loss
+
+
+def build_models(map_size=128, out_dim=128, cell_feat_dim=36, net_feat_dim=2, cnn_outdim=128, pooling='max',
+                 nlabels=1, device='cuda', seed=9294, unet=True):
+    """init_model (src/train.py:34-93) for the defaults of src/options.py with --unet."""
+    import model as M
+    import Unet as U
+    torch.manual_seed(seed)                                                     # src/train.py:596-598
+    gnn = M.PathConv(out_feat_dim=out_dim, hidden_feat_dim=out_dim, cell_feat_dim=cell_feat_dim,
+                     net_feat_dim=net_feat_dim, flag_attn=False, num_heads=1)
+    cnn = U.UNet(pooling) if unet else M.LayoutNet(pooling)
+    fcn = nn.Linear(map_size * map_size, cnn_outdim)
+    nn.init.xavier_uniform_(fcn.weight, gain=nn.init.calculate_gain('relu'))    # src/train.py:72-73
+    mlp_dim = out_dim + cnn_outdim + 32                                          # D2: global_dim is 32
+    mlp = M.MLP(mlp_dim, mlp_dim * 2, nlabels)
+    pmodel = M.PathModel(gnn, None, fcn, None, None, mlp)                        # D1
+    return pmodel.to(device), cnn.to(device)
+
+
+def trainable_parameters(pmodel, cnn):
+    """Parameters that receive gradients (fc_net_drive / fc_attn2 are unused in forward: torch's Adam skips
+    them because their .grad stays None, src/model.py:52-54)."""
+    skip = ('gnn.fc_net_drive.', 'gnn.fc_attn2.')
+    ps = [p for n, p in pmodel.named_parameters() if not n.startswith(skip)]
+    if cnn is not None:
+        ps += list(cnn.parameters())
+    return ps
+
+
+class DesignBatch:
+    """B designs resident on the device, merged block-diagonally."""
+
+    def __init__(self, designs, device, out_dim=128):
+        self.designs = designs
+        self.B = len(designs)
+        self.device = torch.device(device)
+        graphs = [PinGraph.from_synth(d) for d in designs]
+        g = graphs[0] if self.B == 1 else PinGraph.batch(graphs)
+        self.graph = g.to(device)
+        self.N = self.graph.number_of_nodes()
+        self.out_dim = out_dim
+        self.L = max(d.L for d in designs)
+        self.node_off = np.concatenate([[0], np.cumsum([d.N for d in designs])]).astype(np.int64)
+        self.path_off = np.concatenate([[0], np.cumsum([d.num_paths for d in designs])]).astype(np.int64)
+        self.P = designs[0].map_size ** 2
+        # same-index levels concatenated; python int lists, as the reference passes them (src/dataset.py:124-129)
+        self.level_nodes = []
+        for l in range(self.L):
+            parts = [d.levels[l] + self.node_off[i] for i, d in enumerate(designs) if l < d.L]
+            self.level_nodes.append(np.concatenate(parts).tolist())
+        masks = [PathMasks(d.mask_indptr, d.mask_cols, d.map_size ** 2, device) for d in designs]
+        self.masks = masks[0] if self.B == 1 else PathMasks.batch(masks)
+        self.images = torch.from_numpy(np.stack([d.image for d in designs])).to(device)
+        self.arrival = self.graph.ndata['arrival_time']
+        self.required = self.graph.ndata['required_time']
+        self.level_th = [torch.tensor([float(l)], device=device) for l in range(self.L)]
+        self.path2level = np.concatenate([d.path2level for d in designs])
+        self.path2endpoint = np.concatenate([d.path2endpoint + self.node_off[i] for i, d in enumerate(designs)])
+        self.path2design = np.concatenate([np.full(d.num_paths, i, dtype=np.int64) for i, d in enumerate(designs)])
+
+    def select(self, path_ids_per_design):
+        """Bucket the sampled paths by level (src/train.py:476-484); order inside a level = design, then
+        order of appearance.  One host->device copy for the whole step."""
+        gp = np.concatenate([np.asarray(p, dtype=np.int64) + self.path_off[i]
+                             for i, p in enumerate(path_ids_per_design)])
+        lv = self.path2level[gp]
+        order = np.argsort(lv, kind='stable')
+        gp, lv = gp[order], lv[order]
+        ends = self.path2endpoint[gp]
+        counts = np.bincount(lv, minlength=self.L)
+        packed = np.stack([ends, gp, self.path2design[gp] * self.P]).astype(np.int32)
+        dev = torch.from_numpy(packed).to(self.device)
+        return dev[0], dev[1], dev[2], counts, ends
+
+
+class TrainStep:
+    def __init__(self, pmodel, cnn, designs, device, lr=1e-3, weight_decay=0.0, fused_optimizer=True, world_size=1):
+        self.pmodel, self.cnn = pmodel, cnn
+        self.device = torch.device(device)
+        self.batch = DesignBatch(designs, device, pmodel.gnn.out_feat_dim if pmodel.gnn is not None else 128)
+        self.world_size = world_size
+        if cnn is not None and hasattr(cnn, 'set_per_sample_stats'):
+            cnn.set_per_sample_stats(self.batch.B > 1)
+        params = trainable_parameters(pmodel, cnn)
+        self.fused = fused_optimizer
+        if fused_optimizer:
+            self.optim = FlatAdam(params, lr=lr, weight_decay=weight_decay)
+        else:
+            self.optim = torch.optim.Adam(params, lr, weight_decay=weight_decay)     # src/train.py:431-435
+        pmodel.train()
+        if cnn is not None:
+            cnn.train()
+        self.h = torch.zeros((self.batch.N, self.batch.out_dim), dtype=torch.float32, device=self.device)
+
+    # ---------------------------------------------------------------- forward of one mini-batch
+    def forward(self, path_ids_per_design):
+        b, g = self.batch, self.batch.graph
+        ends_d, paths_d, foff_d, counts, ends_h = b.select(path_ids_per_design)
+        feat = self.cnn(b.images).reshape(b.B, -1) if self.cnn is not None else None      # src/train.py:465,562
+        self.h.zero_()                                                                    # src/train.py:342,559
+        g.ndata['h'] = self.h
+        hats, pos = [], 0
+        for level_id in range(b.L):                                                       # src/train.py:490-511
+            k = int(counts[level_id])
+            targets = ends_d[pos:pos + k]
+            path_map = None
+            if k and feat is not None:
+                path_map = MaskedPathMap(b.masks, paths_d[pos:pos + k], feat,
+                                         foff_d[pos:pos + k] if b.B > 1 else None)
+            cur = self.pmodel(g, b.level_nodes[level_id], None, targets, level_id, b.level_th[level_id], path_map)
+            pos += k
+            if cur is not None:
+                hats.append(cur)
+        return torch.cat(hats, 0), ends_d, ends_h
+
+    def step(self, path_ids_per_design):
+        """One mini-batch: forward, MSE on arrival time, backward, (all-reduce,) Adam.
+        Returns (loss tensor, predictions, target node ids)."""
+        hats, ends_d, ends_h = self.forward(path_ids_per_design)
+        arrival = self.batch.arrival[ends_d.long()].squeeze(-1)                            # src/train.py:520-522
+        loss = mse_loss(hats, arrival)
+        self.optim.zero_grad()
+        loss.backward()
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.optim.flat_grad)
+            self.optim.step(gscale=1.0 / self.world_size)
+        else:
+            self.optim.step()
+        return loss.detach(), hats.detach(), ends_h.tolist()

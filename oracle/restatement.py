@@ -280,7 +280,7 @@ class OracleTrainer:
         self.optim.zero_grad()
         loss.backward()
         self.optim.step()
-        return float(loss), hats.detach(), target_list
+        return float(loss.detach()), hats.detach(), target_list
 
 
 def r2_score(pred, target):
