@@ -1,0 +1,223 @@
+"""bench.py - train-step throughput of the multimodal-fusion hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one reference-shaped mini-batch (src/train.py:475-562) over a batch of synthetic designs:
+U-Net forward, L-level netlist sweep, fusion head, MSE, full backward, Adam (plus one RCCL all-reduce of the
+flat gradient buffer when N > 1).  Workload at N=1 is BASELINE.json configs[1] / SURVEY.md §8d config B:
+8 designs per step, each 65 536 nodes / 64 levels / 256x256 layout tile / 1350 endpoints, fp32 arithmetic.
+Inputs (graphs, features, masks, images) are resident in HBM before the timed region.  Data parallel =
+designs sharded over ranks (weak scaling: every rank steps its own 8 designs).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      dominant kernel by device time: algorithmic flops (or bytes) / launch duration, both from
+                HIP events recorded by the library on the launch stream (mmft_prof_*), in a separate
+                instrumented region of the same steps so that `value` is not perturbed by the events;
+  cpu_baseline  the CPU oracle (oracle/restatement.py, kind "port") timed on this host on a bounded
+                sample (one design per step as the reference does, 1 warm-up + 2 timed steps).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, 'multimodal-fusion-based-pre-routing-timing-prediction-_amd')
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_MFMA_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA, dense
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
+
+
+def log(msg):
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
+def sample_paths(designs, batch_paths, rng):
+    return [rng.permutation(d.num_paths)[:min(batch_paths, d.num_paths)] for d in designs]
+
+
+def prof_report():
+    from mmft import lib
+    L = lib.load()
+    need = L.mmft_prof_report(None, 0)
+    buf = ctypes.create_string_buffer(need + 16)
+    L.mmft_prof_report(ctypes.cast(buf, ctypes.c_void_p), need + 16)
+    rows = []
+    for line in buf.value.decode().splitlines():
+        name, n, ms, fl, by = line.split('\t')
+        rows.append(dict(name=name, launches=int(n), ms=float(ms), flops=float(fl), bytes=float(by)))
+    return rows
+
+
+def cpu_baseline(design, pm_state, pc_state, batch_paths, steps=2):
+    """The CPU oracle's train step (reference-shaped: one design per step), timed on this host's cores."""
+    from oracle import restatement as R
+    # the GPU box gives one GPU's share of the host: 16 cores (more threads than that only oversubscribe)
+    ncores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+    torch.set_num_threads(ncores)
+    log(f'cpu oracle on {ncores} threads (os.cpu_count() = {os.cpu_count()})')
+    orc = R.OracleTrainer(pm_state, pc_state)
+    csr = R.design_csr(design)
+    rng = np.random.default_rng(7)
+    t = []
+    for i in range(steps + 1):
+        ids = rng.permutation(design.num_paths)[:min(batch_paths, design.num_paths)].tolist()
+        t0 = time.perf_counter()
+        orc.step(design, csr, ids)
+        t.append(time.perf_counter() - t0)
+        log(f'cpu oracle step {i}: {t[-1]:.2f} s')
+    sec = float(np.mean(t[1:]))
+    return dict(value=1.0 / sec, unit='designs/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{steps} timed steps (+1 warm-up) of ONE config-B design per step, fp32 torch CPU, '
+                       f'anomaly detection off; {sec:.2f} s/step')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--designs', type=int, default=8, help='designs per rank per step (config B: 8)')
+    ap.add_argument('--nodes', type=int, default=65536)
+    ap.add_argument('--levels', type=int, default=64)
+    ap.add_argument('--tile', type=int, default=256)
+    ap.add_argument('--batch-paths', type=int, default=1350)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the hot path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)          # backend "nccl" is RCCL on ROCm
+
+    from mmft.synth import synth_design
+    from mmft.train import build_models, TrainStep
+    from mmft import lib
+
+    designs = [synth_design(N=args.nodes, L=args.levels, tile=args.tile, seed=9294 + rank * args.designs + i)
+               for i in range(args.designs)]
+    log(f'rank {rank}: {len(designs)} designs generated')
+    pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=9294)
+    pm_state = {k: v.detach().cpu().clone() for k, v in pmodel.state_dict().items()}
+    pc_state = {k: v.detach().cpu().clone() for k, v in cnn.state_dict().items()}
+    ts = TrainStep(pmodel, cnn, designs, dev, world_size=world)
+    rng = np.random.default_rng(1234 + rank)
+    log('resident on device; warm-up')
+
+    for _w in range(args.warmup):
+        ts.step(sample_paths(designs, args.batch_paths, rng))
+        torch.cuda.synchronize()
+        log(f'warm-up step {_w} done')
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tl = []
+    for _it in range(args.steps):
+        loss, hats, tl = ts.step(sample_paths(designs, args.batch_paths, rng))
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    log(f'timed region: {elapsed / args.steps * 1e3:.2f} ms/step')
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    mae = float((hats - ts.batch.arrival[torch.as_tensor(tl, device=dev).long()].squeeze(-1)).abs().mean())
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        L = lib.load()
+        L.mmft_prof_reset()
+        L.mmft_prof_enable(1)
+        nprof = min(args.steps, 3)
+        for _i in range(nprof):
+            ts.step(sample_paths(designs, args.batch_paths, rng))
+        torch.cuda.synchronize()
+        L.mmft_prof_enable(0)
+        log('profiled steps done')
+        rows = sorted(prof_report(), key=lambda r: -r['ms'])
+        L.mmft_prof_reset()
+        total_ms = sum(r['ms'] for r in rows)
+        top = rows[0]
+        per_launch_ms = top['ms'] / top['launches']
+        if top['flops'] > 0:
+            ach = top['flops'] / (top['ms'] * 1e-3) / 1e12
+            roofline = dict(bound='mfma', achieved=ach, peak=PEAK_MFMA_F32_TFLOPS, unit='TFLOP/s',
+                            frac=ach / PEAK_MFMA_F32_TFLOPS, traffic=None)
+        else:
+            ach = top['bytes'] / (top['ms'] * 1e-3) / 1e9
+            roofline = dict(bound='hbm', achieved=ach, peak=PEAK_HBM_GBS, unit='GB/s', frac=ach / PEAK_HBM_GBS,
+                            traffic=None)
+        roofline.update(kernel=top['name'], launches_per_step=top['launches'] / nprof,
+                        avg_launch_us=per_launch_ms * 1e3, share_of_device_time=top['ms'] / total_ms,
+                        device_ms_per_step=total_ms / nprof,
+                        top5=[dict(kernel=r['name'], ms_per_step=r['ms'] / nprof, launches=r['launches'] // nprof,
+                                   tflops=(r['flops'] / (r['ms'] * 1e-3) / 1e12) if r['ms'] > 0 else 0.0)
+                              for r in rows[:5]])
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log('timing the CPU oracle (bounded sample)')
+        cpu = cpu_baseline(designs[0], pm_state, pc_state, args.batch_paths)
+
+    if rank == 0:
+        total_designs = args.designs * world * args.steps
+        value = total_designs / elapsed
+        out = {
+            'metric': 'train-step samples/sec',
+            'value': value,
+            'unit': 'designs/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {
+                'workload': f'config B: {args.designs} designs/step/GPU, {args.nodes}-node netlist, {args.levels} levels, '
+                            f'{args.tile}x{args.tile} tile, {args.batch_paths} endpoints/design, UNet(max), fp32',
+                'designs_per_step_per_gpu': args.designs, 'nodes': args.nodes, 'levels': args.levels,
+                'tile': args.tile, 'endpoints_per_design': args.batch_paths,
+                'parallelism': f'dp{world} (designs sharded, one all-reduce of the flat gradient per step)',
+                'api': 'drop-in per-level model() calls',
+            },
+            'nodes_per_s': value * args.nodes,
+            'pixels_per_s': value * args.tile * args.tile,
+            'train_mae_last_step': mae,
+            'loss_last_step': float(loss),
+            'roofline': roofline,
+            'cpu_baseline': cpu,
+        }
+        if cpu is not None:
+            out['speedup_vs_cpu_baseline'] = value / cpu['value']
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -32,6 +32,13 @@ extern "C" {
 
 int mmft_version(void);
 const char* mmft_last_error(void);
+/* Launch profiling for bench.py's roofline line: while enabled, every instrumented kernel launch is
+ * bracketed by HIP events on ITS launch stream; mmft_prof_report writes one line per kernel name
+ * ("name\tlaunches\ttotal_ms\talgorithmic_flops\talgorithmic_bytes") and returns the size needed.
+ * mmft_prof_report synchronises on the recorded events (the only entry point that waits). */
+int mmft_prof_enable(int on);
+int mmft_prof_reset(void);
+int mmft_prof_report(char* buf, int cap);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense layers  --  replaces th.nn.Linear / LeakyReLU inside MLP (src/model.py:10-24), used by

@@ -40,6 +40,23 @@ inline int check_launch(const char* what) {
     }                                      \
   } while (0)
 
+// Optional launch profiling (mmft_prof_enable): HIP events recorded on the launch stream around every
+// instrumented kernel, aggregated per kernel name by mmft_prof_report.  Off by default (zero overhead
+// beyond one branch per launch).
+bool prof_on();
+void prof_begin(const char* name, double flops, double bytes, hipStream_t st);
+void prof_end(hipStream_t st);
+struct ProfScope {
+  hipStream_t st;
+  bool on;
+  ProfScope(const char* name, double flops, double bytes, hipStream_t s) : st(s), on(prof_on()) {
+    if (on) prof_begin(name, flops, bytes, st);
+  }
+  ~ProfScope() {
+    if (on) prof_end(st);
+  }
+};
+
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -147,6 +147,7 @@ int mmft_masked_fc_fwd(const int* mask_indptr, const int* mask_cols, const int* 
   MMFT_REQUIRE(aligned16(wT) && aligned16(out) && (!bias || aligned16(bias)), "masked_fc_fwd: 16-byte alignment");
   if (T == 0) return MMFT_OK;
   DeviceGuard dg(device);
+  ProfScope ps("masked_fc_fwd_kernel", 0.0, 0.0, (hipStream_t)stream);
   hipLaunchKernelGGL(masked_fc_fwd_kernel, dim3(ew_grid((long long)T * (Dout / 4))), dim3(256), 0, (hipStream_t)stream,
                      mask_indptr, mask_cols, paths, f_off, T, f, wT, bias, out, Dout);
   return check_launch("masked_fc_fwd");
@@ -158,6 +159,7 @@ int mmft_masked_fc_bwd_scatter(const int* mask_indptr, const int* mask_cols, con
   MMFT_REQUIRE(T >= 0 && P > 0 && Dout > 0, "masked_fc_bwd_scatter: bad sizes");
   if (T == 0) return MMFT_OK;
   DeviceGuard dg(device);
+  ProfScope ps("masked_fc_bwd_scatter_kernel", 0.0, 0.0, (hipStream_t)stream);
   hipLaunchKernelGGL(masked_fc_bwd_scatter_kernel, dim3(ew_grid((long long)T * Dout)), dim3(256), 0, (hipStream_t)stream,
                      mask_indptr, mask_cols, paths, f_off, T, gout, S, Dout);
   return check_launch("masked_fc_bwd_scatter");
@@ -167,6 +169,7 @@ int mmft_masked_fc_bwd_finish(const float* S, const float* f, const float* w, fl
                               int Dout, int device, void* stream) {
   MMFT_REQUIRE(S && f && w && dw && df && B > 0 && P > 0 && Dout > 0, "masked_fc_bwd_finish: bad args");
   DeviceGuard dg(device);
+  ProfScope ps("masked_fc_bwd_finish_kernel", 0.0, 4.0 * ((double)B * P * Dout + 2.0 * P * Dout), (hipStream_t)stream);
   hipLaunchKernelGGL(masked_fc_bwd_finish_kernel, dim3(cdiv(P, 32)), dim3(256), 0, (hipStream_t)stream, S, f, w, dw, df, B, P,
                      Dout);
   return check_launch("masked_fc_bwd_finish");
@@ -186,6 +189,7 @@ int mmft_adam_step(float* p, const float* g, float* m, float* v, long long n, fl
   MMFT_REQUIRE(bias_correction1 > 0.f && bias_correction2 > 0.f, "adam_step: bias corrections must be positive");
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
+  ProfScope ps("adam_kernel", 0.0, 28.0 * n, (hipStream_t)stream);
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr / bias_correction1,
                      beta1, beta2, eps, weight_decay, sqrtf(bias_correction2), gscale);
   return check_launch("adam_step");

@@ -36,6 +36,7 @@ struct TileCfg {
 // KM loaders: ctx(m4) once per thread-column group, load(ctx, k, kend) -> X[k][m..m+3]
 
 struct DenseMK {
+  static const char* name() { return "DenseMK"; }
   static constexpr bool KMAJOR = false;
   const float* p;
   const int* idx;  // optional row gather
@@ -68,6 +69,7 @@ struct DenseMK {
 };
 
 struct DenseKM {
+  static const char* name() { return "DenseKM"; }
   static constexpr bool KMAJOR = true;
   const float* p;
   const int* kidx;  // optional gather on the reduction rows
@@ -94,6 +96,7 @@ struct DenseKM {
 
 // NHWC implicit-GEMM A operand: X[m = pixel][k = (tap, ci)], C % 4 == 0
 struct Im2colMK {
+  static const char* name() { return "Im2colMK"; }
   static constexpr bool KMAJOR = false;
   const float* p;
   int H, W, C, KH, KW, pad;
@@ -132,6 +135,7 @@ struct Im2colMK {
 
 // wgrad B operand: X[k = pixel][n = (tap, ci)] gathered from the NHWC input, C % 4 == 0
 struct Im2colKM {
+  static const char* name() { return "Im2colKM"; }
   static constexpr bool KMAJOR = true;
   const float* p;
   int H, W, C, KH, KW, pad;
@@ -170,6 +174,7 @@ struct Im2colKM {
 // scalar variants for channel counts that are not a multiple of 4 (first conv of UNet: Ci = 3,
 // LayoutNet: Ci = 2, dgrad of the 1-channel heads: "Ci" = 1); every element decodes its own tap
 struct Im2colMKScalar {
+  static const char* name() { return "Im2colMKScalar"; }
   static constexpr bool KMAJOR = false;
   const float* p;
   int H, W, C, KH, KW, pad;
@@ -196,6 +201,7 @@ struct Im2colMKScalar {
 };
 
 struct Im2colKMScalar {
+  static const char* name() { return "Im2colKMScalar"; }
   static constexpr bool KMAJOR = true;
   const float* p;
   int H, W, C, KH, KW, pad;
@@ -415,6 +421,18 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(XL xl, WL wl, Epi epi, in
 
 // ------------------------------------------------------------------------------------ dispatch
 template <class CFG, class XL, class WL>
+inline const char* gemm_kernel_name() {
+  static char buf[192];
+  static bool init = false;
+  if (!init) {
+    snprintf(buf, sizeof(buf), "gemm_f32_kernel<TileCfg<%d,%d,%d,%d,%d>,%s,%s>", CFG::BM, CFG::BN, CFG::BK, CFG::WM, CFG::WN,
+             XL::name(), WL::name());
+    init = true;
+  }
+  return buf;
+}
+
+template <class CFG, class XL, class WL>
 inline void launch_cfg(const XL& xl, const WL& wl, const Epi& epi, int M, int N, int K, int splits, hipStream_t st) {
   int ksplit = K;
   if (splits > 1) {
@@ -423,6 +441,8 @@ inline void launch_cfg(const XL& xl, const WL& wl, const Epi& epi, int M, int N,
     splits = (K + ksplit - 1) / ksplit;
   }
   dim3 grid(cdiv(M, CFG::BM), cdiv(N, CFG::BN), splits);
+  // algorithmic work of this launch: 2*M*N*K flops; bytes = the three matrices touched once
+  ProfScope ps(gemm_kernel_name<CFG, XL, WL>(), 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), st);
   hipLaunchKernelGGL((gemm_f32_kernel<CFG, XL, WL>), grid, dim3(256), 0, st, xl, wl, epi, M, N, K, ksplit);
 }
 

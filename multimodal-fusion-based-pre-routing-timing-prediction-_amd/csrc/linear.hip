@@ -1,6 +1,7 @@
 // Dense layers on the fp32 MFMA engine: forward, dgrad, wgrad, bias-gradient column sums, activations.
 // Replaces th.nn.Linear / LeakyReLU inside MLP (reference src/model.py:10-24).
 #include "gemm_engine.h"
+#include <string.h>
 
 namespace mmft {
 
@@ -11,6 +12,46 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// ---------------------------------------------------------------- launch profiling
+}  // namespace mmft
+#include <mutex>
+#include <string>
+#include <vector>
+#include <map>
+namespace mmft {
+struct ProfRec {
+  const char* name;
+  double flops, bytes;
+  hipEvent_t e0, e1;
+};
+static bool g_prof = false;
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+static ProfRec g_open;
+
+bool prof_on() { return g_prof; }
+static hipEvent_t prof_event() {
+  if (!g_pool.empty()) {
+    hipEvent_t e = g_pool.back();
+    g_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void prof_begin(const char* name, double flops, double bytes, hipStream_t st) {
+  g_prof_mu.lock();                       // held until prof_end: launches are serialised while profiling
+  g_open = ProfRec{name, flops, bytes, prof_event(), prof_event()};
+  (void)hipEventRecord(g_open.e0, st);
+}
+void prof_end(hipStream_t st) {
+  (void)hipEventRecord(g_open.e1, st);
+  g_recs.push_back(g_open);
+  g_prof_mu.unlock();
 }
 
 // ---------------------------------------------------------------- split-K slab combine
@@ -26,6 +67,7 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
 }
 
 int launch_slab_reduce(const float* slabs, int splits, long long elems, float* out, int accumulate, hipStream_t st) {
+  ProfScope ps("slab_reduce_kernel", 0.0, 4.0 * (splits + 1.0) * elems, st);
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(ew_grid(elems)), dim3(256), 0, st, slabs, splits, elems, out, accumulate);
   return check_launch("slab_reduce");
 }
@@ -84,6 +126,52 @@ using namespace mmft;
 extern "C" {
 
 int mmft_version(void) { return 100; }
+
+int mmft_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(mmft::g_prof_mu);
+  mmft::g_prof = on != 0;
+  return MMFT_OK;
+}
+
+int mmft_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(mmft::g_prof_mu);
+  for (auto& r : mmft::g_recs) {
+    mmft::g_pool.push_back(r.e0);
+    mmft::g_pool.push_back(r.e1);
+  }
+  mmft::g_recs.clear();
+  return MMFT_OK;
+}
+
+// one line per kernel name: name \t launches \t total_ms \t flops \t bytes ; returns bytes written (or needed)
+int mmft_prof_report(char* buf, int cap) {
+  std::lock_guard<std::mutex> lk(mmft::g_prof_mu);
+  struct Agg { long long n = 0; double ms = 0, flops = 0, bytes = 0; };
+  std::map<std::string, Agg> agg;
+  for (auto& r : mmft::g_recs) {
+    (void)hipEventSynchronize(r.e1);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = 0.f;
+    Agg& a = agg[r.name];
+    a.n++;
+    a.ms += ms;
+    a.flops += r.flops;
+    a.bytes += r.bytes;
+  }
+  std::string out;
+  char line[512];
+  for (auto& kv : agg) {
+    snprintf(line, sizeof(line), "%s\t%lld\t%.6f\t%.6e\t%.6e\n", kv.first.c_str(), kv.second.n, kv.second.ms,
+             kv.second.flops, kv.second.bytes);
+    out += line;
+  }
+  if (buf && cap > 0) {
+    int n = (int)out.size() < cap - 1 ? (int)out.size() : cap - 1;
+    memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
+  return (int)out.size() + 1;
+}
 const char* mmft_last_error(void) { return mmft::g_err; }
 
 int mmft_linear_fwd(const float* x, const int* xidx, long long ldx, const float* w, long long ldw, const float* bias,
@@ -183,7 +271,10 @@ int mmft_colsum(const float* g, const int* idx, long long ld, int rows, int cols
   MMFT_REQUIRE(workspace && workspace_bytes >= (long long)nb * cols * 4, "colsum: workspace too small");
   int rpb = cdiv(rows, nb);
   nb = cdiv(rows, rpb);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, g, idx, ld, rows, cols, rpb, workspace);
+  {
+    ProfScope ps("colsum_partial_kernel", 0.0, 4.0 * rows * cols, st);   // scoped: slab_reduce below has its own
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, g, idx, ld, rows, cols, rpb, workspace);
+  }
   int rc = check_launch("colsum_partial");
   if (rc) return rc;
   return launch_slab_reduce(workspace, nb, cols, out, accumulate, st);
@@ -194,6 +285,7 @@ int mmft_act_bwd(const float* dy, const float* y, float* dpre, long long n, int 
   MMFT_REQUIRE(dy && y && dpre && n >= 0, "act_bwd: bad args");
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
+  ProfScope ps("act_bwd_kernel", 0.0, 12.0 * n, (hipStream_t)stream);
   hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dpre, n, act, slope);
   return check_launch("act_bwd");
 }
