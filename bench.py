@@ -91,6 +91,7 @@ def main():
     ap.add_argument('--levels', type=int, default=64)
     ap.add_argument('--tile', type=int, default=256)
     ap.add_argument('--batch-paths', type=int, default=1350)
+    ap.add_argument('--mode', default='sweep', choices=['sweep', 'dropin'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -117,7 +118,7 @@ def main():
     pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=9294)
     pm_state = {k: v.detach().cpu().clone() for k, v in pmodel.state_dict().items()}
     pc_state = {k: v.detach().cpu().clone() for k, v in cnn.state_dict().items()}
-    ts = TrainStep(pmodel, cnn, designs, dev, world_size=world)
+    ts = TrainStep(pmodel, cnn, designs, dev, world_size=world, mode=args.mode)
     rng = np.random.default_rng(1234 + rank)
     log('resident on device; warm-up')
 
@@ -159,6 +160,10 @@ def main():
         rows = sorted(prof_report(), key=lambda r: -r['ms'])
         L.mmft_prof_reset()
         total_ms = sum(r['ms'] for r in rows)
+        for r in rows[:40]:
+            log('  %-70s %5d launches/step %8.3f ms/step %7.1f us/launch %7.2f TF %8.1f GB/s' % (
+                r['name'][:70], r['launches'] // nprof, r['ms'] / nprof, r['ms'] / r['launches'] * 1e3,
+                r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] else 0, r['bytes'] / (r['ms'] * 1e-3) / 1e9 if r['ms'] else 0))
         top = rows[0]
         per_launch_ms = top['ms'] / top['launches']
         if top['flops'] > 0:
@@ -203,7 +208,7 @@ def main():
                 'designs_per_step_per_gpu': args.designs, 'nodes': args.nodes, 'levels': args.levels,
                 'tile': args.tile, 'endpoints_per_design': args.batch_paths,
                 'parallelism': f'dp{world} (designs sharded, one all-reduce of the flat gradient per step)',
-                'api': 'drop-in per-level model() calls',
+                'api': 'PathModel.forward_sweep (whole-sweep entry; per-level drop-in path: --mode dropin)' if args.mode == 'sweep' else 'drop-in per-level model() calls',
             },
             'nodes_per_s': value * args.nodes,
             'pixels_per_s': value * args.tile * args.tile,

@@ -176,12 +176,16 @@ int mmft_transpose(const float* src, float* dst, int R, int C, int device, void*
 int mmft_masked_fc_fwd(const int* mask_indptr, const int* mask_cols, const int* paths, const int* f_off, int T,
                        const float* f, const float* wT, const float* bias, float* out, int P, int Dout,
                        int device, void* stream);
-/* S[f_off[t]+p][:] += gout[t][:] for every p in mask(paths[t])   (S is [B*P][Dout], zeroed by the caller) */
-int mmft_masked_fc_bwd_scatter(const int* mask_indptr, const int* mask_cols, const int* paths, const int* f_off,
-                               int T, const float* gout, float* S, int P, int Dout, int device, void* stream);
-/* dw[c][p] = sum_b f[b][p]*S[b][p][c];  df[b][p] = sum_c w[c][p]*S[b][p][c]   (w, dw are [Dout][P]) */
-int mmft_masked_fc_bwd_finish(const float* S, const float* f, const float* w, float* dw, float* df,
-                              int B, int P, int Dout, int device, void* stream);
+/* Backward of the masked projection as a deterministic GATHER over the transposed masks (no atomics):
+ * csc_indptr[B*P+1] / csc_paths[nnz] list, for every map cell (b, p), the path ids whose mask covers it
+ * (ascending); first[q] is the first batch row holding path q (-1: not sampled) and next[t] the next batch
+ * row with the same path (-1: none), so duplicates from oversampling are summed in batch order.
+ *   S = sum_{t : p in mask(paths[t]), design(t) = b} gout[t][:]
+ *   dwT[p][:] = sum_b f[b][p] * S      (transposed weight gradient, [P][Dout])
+ *   df[b][p]  = sum_c w T[p][c] * S[c]                                      */
+int mmft_masked_fc_bwd(const int* csc_indptr, const int* csc_paths, const int* first, const int* next,
+                       const float* gout, const float* f, const float* wT, float* dwT, float* df,
+                       int B, int P, int Dout, int device, void* stream);
 /* loss = mean((pred-target)^2); grad[i] = 2*(pred[i]-target[i])/n   (single workgroup, n <= 2^24) */
 int mmft_mse_fwd_bwd(const float* pred, const float* target, int n, float* loss, float* grad,
                      int device, void* stream);

@@ -23,73 +23,73 @@ __global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict_
   }
 }
 
-// one thread per (path row t, 4-channel group): gathers 16-B pieces of wT rows, like the graph kernels
+// one workgroup per batch row t: 256 threads = J nnz lanes x (Dout/4) channel groups; every thread gathers
+// 16-B pieces of wT rows for its share of the mask's non-zeros, partial sums are combined through LDS
 __global__ void __launch_bounds__(256) masked_fc_fwd_kernel(const int* __restrict__ indptr, const int* __restrict__ cols,
                                                             const int* __restrict__ paths,
                                                             const int* __restrict__ foff, int T,
                                                             const float* __restrict__ f, const float* __restrict__ wT,
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             int Dout) {
+  __shared__ f32x4 part[256];
   const int groups = Dout >> 2;
-  const long long total = (long long)T * groups;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    int t = (int)(i / groups), c = (int)(i - (long long)t * groups) * 4;
+  const int J = 256 / groups;
+  const int t = blockIdx.x;
+  const int j = threadIdx.x / groups, c4 = threadIdx.x - j * groups;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (j < J) {
     int q = paths[t];
     const float* fb = f + (foff ? foff[t] : 0);
-    f32x4 acc = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int e = indptr[q]; e < indptr[q + 1]; ++e) {
+    int e1 = indptr[q + 1];
+    for (int e = indptr[q] + j; e < e1; e += J) {
       int p = cols[e];
-      acc += *reinterpret_cast<const f32x4*>(wT + (long long)p * Dout + c) * fb[p];
+      acc += *reinterpret_cast<const f32x4*>(wT + (long long)p * Dout + c4 * 4) * fb[p];
     }
-    *reinterpret_cast<f32x4*>(out + (long long)t * Dout + c) = acc;
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < groups) {
+    f32x4 s = bias ? *reinterpret_cast<const f32x4*>(bias + threadIdx.x * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int jj = 0; jj < J; ++jj) s += part[jj * groups + threadIdx.x];      // fixed order: reproducible
+    *reinterpret_cast<f32x4*>(out + (long long)t * Dout + threadIdx.x * 4) = s;
   }
 }
 
-// one thread per (t, channel): each wave-instruction adds 256 contiguous bytes of one S row
-__global__ void __launch_bounds__(256) masked_fc_bwd_scatter_kernel(const int* __restrict__ indptr,
-                                                                    const int* __restrict__ cols,
-                                                                    const int* __restrict__ paths,
-                                                                    const int* __restrict__ foff, int T,
-                                                                    const float* __restrict__ gout,
-                                                                    float* __restrict__ S, int Dout) {
-  const long long total = (long long)T * Dout;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    int t = (int)(i / Dout), c = (int)(i - (long long)t * Dout);
-    int q = paths[t];
-    float g = gout[i];
-    float* Sb = S + (long long)(foff ? foff[t] : 0) * Dout;
-    for (int e = indptr[q]; e < indptr[q + 1]; ++e) atomicAdd(Sb + (long long)cols[e] * Dout + c, g);
-  }
-}
-
-// block = 32 columns p x all channels; dw written coalesced along p, df by an LDS column reduction
-__global__ void __launch_bounds__(256) masked_fc_bwd_finish_kernel(const float* __restrict__ S, const float* __restrict__ f,
-                                                                   const float* __restrict__ w, float* __restrict__ dw,
-                                                                   float* __restrict__ df, int B, int P, int Dout) {
-  __shared__ float part[8][32];
-  int p = blockIdx.x * 32 + (threadIdx.x & 31);
-  int cy = threadIdx.x >> 5;                      // 8 channel lanes
-  if (p < P)
-    for (int c = cy; c < Dout; c += 8) dw[(long long)c * P + p] = 0.f;
+// one thread per (map cell p, 4-channel group), looping over the designs b: gathers the batch rows covering
+// cell (b,p) through the transposed masks (fixed order -> bitwise reproducible); df by an LDS reduction
+__global__ void __launch_bounds__(256) masked_fc_bwd_kernel(const int* __restrict__ cptr, const int* __restrict__ cpaths,
+                                                            const int* __restrict__ first, const int* __restrict__ next,
+                                                            const float* __restrict__ gout, const float* __restrict__ f,
+                                                            const float* __restrict__ wT, float* __restrict__ dwT,
+                                                            float* __restrict__ df, int B, int P, int Dout) {
+  __shared__ float red[256];
+  const int groups = Dout >> 2;
+  const int cells_per_block = 256 / groups;
+  const int lc = threadIdx.x / groups;
+  const int p = blockIdx.x * cells_per_block + lc;
+  const int c4 = threadIdx.x - lc * groups;
+  const bool valid = lc < cells_per_block && p < P;
+  f32x4 w = {0.f, 0.f, 0.f, 0.f}, dw = {0.f, 0.f, 0.f, 0.f};
+  if (valid) w = *reinterpret_cast<const f32x4*>(wT + (long long)p * Dout + c4 * 4);
   for (int b = 0; b < B; ++b) {
-    float acc = 0.f;
-    if (p < P) {
-      float fp = f[(long long)b * P + p];
-      for (int c = cy; c < Dout; c += 8) {
-        float s = S[((long long)b * P + p) * Dout + c];
-        dw[(long long)c * P + p] += fp * s;
-        acc += w[(long long)c * P + p] * s;
-      }
+    long long cell = (long long)b * P + p;
+    f32x4 S = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+      for (int e = cptr[cell]; e < cptr[cell + 1]; ++e)
+        for (int t = first[cpaths[e]]; t >= 0; t = next[t])
+          S += *reinterpret_cast<const f32x4*>(gout + (long long)t * Dout + c4 * 4);
+      dw += S * f[cell];
     }
     __syncthreads();
-    part[cy][threadIdx.x & 31] = acc;
+    red[threadIdx.x] = w[0] * S[0] + w[1] * S[1] + w[2] * S[2] + w[3] * S[3];
     __syncthreads();
-    if (threadIdx.x < 32 && p < P) {
-      float s = 0.f;
-      for (int j = 0; j < 8; ++j) s += part[j][threadIdx.x];
-      df[(long long)b * P + p] = s;
+    if (valid && c4 == 0) {
+      float d = 0.f;
+      for (int j = 0; j < groups; ++j) d += red[lc * groups + j];
+      df[cell] = d;
     }
   }
+  if (valid) *reinterpret_cast<f32x4*>(dwT + (long long)p * Dout + c4 * 4) = dw;
 }
 
 __global__ void __launch_bounds__(1024) mse_kernel(const float* __restrict__ pred, const float* __restrict__ target, int n,
@@ -143,36 +143,29 @@ int mmft_transpose(const float* src, float* dst, int R, int C, int device, void*
 int mmft_masked_fc_fwd(const int* mask_indptr, const int* mask_cols, const int* paths, const int* f_off, int T,
                        const float* f, const float* wT, const float* bias, float* out, int P, int Dout, int device, void* stream) {
   MMFT_REQUIRE(mask_indptr && paths && f && wT && out, "masked_fc_fwd: null pointer");
-  MMFT_REQUIRE(T >= 0 && P > 0 && Dout > 0 && Dout % 4 == 0, "masked_fc_fwd: bad sizes (Dout %% 4 == 0)");
+  MMFT_REQUIRE(T >= 0 && P > 0 && Dout > 0 && Dout % 4 == 0 && Dout <= 1024, "masked_fc_fwd: bad sizes (Dout %% 4 == 0, <= 1024)");
   MMFT_REQUIRE(aligned16(wT) && aligned16(out) && (!bias || aligned16(bias)), "masked_fc_fwd: 16-byte alignment");
   if (T == 0) return MMFT_OK;
   DeviceGuard dg(device);
   ProfScope ps("masked_fc_fwd_kernel", 0.0, 0.0, (hipStream_t)stream);
-  hipLaunchKernelGGL(masked_fc_fwd_kernel, dim3(ew_grid((long long)T * (Dout / 4))), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(masked_fc_fwd_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream,
                      mask_indptr, mask_cols, paths, f_off, T, f, wT, bias, out, Dout);
   return check_launch("masked_fc_fwd");
 }
 
-int mmft_masked_fc_bwd_scatter(const int* mask_indptr, const int* mask_cols, const int* paths, const int* f_off, int T,
-                               const float* gout, float* S, int P, int Dout, int device, void* stream) {
-  MMFT_REQUIRE(mask_indptr && paths && gout && S, "masked_fc_bwd_scatter: null pointer");
-  MMFT_REQUIRE(T >= 0 && P > 0 && Dout > 0, "masked_fc_bwd_scatter: bad sizes");
-  if (T == 0) return MMFT_OK;
+int mmft_masked_fc_bwd(const int* csc_indptr, const int* csc_paths, const int* first, const int* next, const float* gout,
+                       const float* f, const float* wT, float* dwT, float* df, int B, int P, int Dout, int device,
+                       void* stream) {
+  MMFT_REQUIRE(csc_indptr && first && next && gout && f && wT && dwT && df, "masked_fc_bwd: null pointer");
+  MMFT_REQUIRE(B > 0 && P > 0 && Dout >= 4 && Dout <= 1024 && Dout % 4 == 0,
+               "masked_fc_bwd: Dout must be a multiple of 4 in [4, 1024]");
+  MMFT_REQUIRE(aligned16(gout) && aligned16(wT) && aligned16(dwT), "masked_fc_bwd: 16-byte alignment");
   DeviceGuard dg(device);
-  ProfScope ps("masked_fc_bwd_scatter_kernel", 0.0, 0.0, (hipStream_t)stream);
-  hipLaunchKernelGGL(masked_fc_bwd_scatter_kernel, dim3(ew_grid((long long)T * Dout)), dim3(256), 0, (hipStream_t)stream,
-                     mask_indptr, mask_cols, paths, f_off, T, gout, S, Dout);
-  return check_launch("masked_fc_bwd_scatter");
-}
-
-int mmft_masked_fc_bwd_finish(const float* S, const float* f, const float* w, float* dw, float* df, int B, int P,
-                              int Dout, int device, void* stream) {
-  MMFT_REQUIRE(S && f && w && dw && df && B > 0 && P > 0 && Dout > 0, "masked_fc_bwd_finish: bad args");
-  DeviceGuard dg(device);
-  ProfScope ps("masked_fc_bwd_finish_kernel", 0.0, 4.0 * ((double)B * P * Dout + 2.0 * P * Dout), (hipStream_t)stream);
-  hipLaunchKernelGGL(masked_fc_bwd_finish_kernel, dim3(cdiv(P, 32)), dim3(256), 0, (hipStream_t)stream, S, f, w, dw, df, B, P,
-                     Dout);
-  return check_launch("masked_fc_bwd_finish");
+  int groups = Dout / 4, cpb = 256 / groups;
+  ProfScope ps("masked_fc_bwd_kernel", 0.0, 0.0, (hipStream_t)stream);
+  hipLaunchKernelGGL(masked_fc_bwd_kernel, dim3(cdiv(P, cpb)), dim3(256), 0, (hipStream_t)stream, csc_indptr, csc_paths,
+                     first, next, gout, f, wT, dwT, df, B, P, Dout);
+  return check_launch("masked_fc_bwd");
 }
 
 int mmft_mse_fwd_bwd(const float* pred, const float* target, int n, float* loss, float* grad, int device, void* stream) {

@@ -45,3 +45,25 @@ class LinearActFn(torch.autograd.Function):
 def linear_act(x, w, b=None, slope=None):
     """act(x @ w.T + b); slope None = no activation, 0 = ReLU, >0 = LeakyReLU(slope)."""
     return LinearActFn.apply(x, w, b, slope)
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """out[i] = table[idx[i]] (idx int32 on the device); backward = atomic scatter-add (duplicates allowed)."""
+
+    @staticmethod
+    def forward(ctx, table, idx):
+        t = table if table.is_contiguous() else table.contiguous()
+        ctx.shape = t.shape
+        ctx.save_for_backward(idx)
+        return ops.gather_rows(t, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        out = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        ops.scatter_add_rows(out, idx, g if g.is_contiguous() else g.contiguous())
+        return out, None
+
+
+def gather_rows(table, idx):
+    return GatherRowsFn.apply(table, idx)

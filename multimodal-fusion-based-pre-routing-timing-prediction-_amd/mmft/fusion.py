@@ -6,47 +6,96 @@ CSR rows + the 1 x P feature map; PathModel recognises it and never builds the d
 path_map tensor (what an unmodified reference loop passes) is still accepted and goes through the dense
 GEMM kernel.
 """
+import numpy as np
 import torch
 from . import lib, ops
 
 
-class PathMasks:
-    """Device CSR of a design's path masks (num_paths x P, 0/1)  (src/verilog_parser_asap7.py:1302-1369)."""
+def _csc_from_csr(indptr, cols, P):
+    """Transposed masks: for every map cell the ascending list of path ids covering it."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    cols = np.asarray(cols, dtype=np.int64)
+    rows = np.repeat(np.arange(indptr.shape[0] - 1, dtype=np.int64), np.diff(indptr))
+    order = np.argsort(cols, kind='stable')
+    cptr = np.zeros(P + 1, dtype=np.int64)
+    np.cumsum(np.bincount(cols, minlength=P), out=cptr[1:])
+    return cptr, rows[order]
 
-    def __init__(self, indptr, cols, P, device):
-        self.indptr = torch.as_tensor(indptr).to(torch.int32).to(device).contiguous()
-        self.cols = torch.as_tensor(cols).to(torch.int32).to(device).contiguous()
-        self.P = int(P)
-        self.num_paths = self.indptr.numel() - 1
-        if self.cols.numel() and (int(self.cols.max()) >= self.P or int(self.cols.min()) < 0):
+
+class PathMasks:
+    """Device CSR (+ transposed CSC) of path masks, num_paths x P, 0/1  (src/verilog_parser_asap7.py:1302-1369).
+
+    For B stacked designs the rows are the designs' paths one after another (global path ids) and the
+    CSC has B*P cells (cell = b*P + p); columns stay in [0, P) because fcn's weight is shared."""
+
+    def __init__(self, indptr, cols, P, device, B=1, row_design=None):
+        ip = np.asarray(torch.as_tensor(indptr).cpu().numpy(), dtype=np.int64)
+        cc = np.asarray(torch.as_tensor(cols).cpu().numpy(), dtype=np.int64)
+        self.P, self.B = int(P), int(B)
+        self.num_paths = ip.shape[0] - 1
+        if cc.size and (cc.max() >= self.P or cc.min() < 0):
             raise ValueError('mask column outside the map')
+        if ip[-1] >= 2 ** 31:
+            raise ValueError('mask nnz exceeds int32')
+        self.host_indptr, self.host_cols = ip, cc
+        self.row_design = np.zeros(self.num_paths, dtype=np.int64) if row_design is None else np.asarray(row_design)
+        self.indptr = torch.from_numpy(ip.astype(np.int32)).to(device)
+        self.cols = torch.from_numpy(cc.astype(np.int32)).to(device)
+        cell = cc + np.repeat(self.row_design, np.diff(ip)) * self.P
+        cptr, cpaths = _csc_from_csr(ip, cell, self.B * self.P)
+        self.csc_indptr = torch.from_numpy(cptr.astype(np.int32)).to(device)
+        self.csc_paths = torch.from_numpy(cpaths.astype(np.int32)).to(device)
 
     @staticmethod
     def batch(masks):
-        """Stack the designs' path rows (path ids offset by the running path count). Columns stay in
-        [0, P): fcn's weight is shared, the per-design feature map is selected through f_off."""
-        ip, cols, off_nnz = [masks[0].indptr[:1]], [], 0
-        for m in masks:
-            if m.P != masks[0].P:
-                raise ValueError('PathMasks.batch: all designs must share the map size')
-            ip.append(m.indptr[1:] + off_nnz)
-            cols.append(m.cols)
-            off_nnz += int(m.cols.numel())
-        return PathMasks(torch.cat(ip), torch.cat(cols), masks[0].P, masks[0].indptr.device)
+        P, dev = masks[0].P, masks[0].indptr.device
+        ip, cols, rd, off = [np.zeros(1, dtype=np.int64)], [], [], 0
+        for b, m in enumerate(masks):
+            if m.P != P or m.B != 1:
+                raise ValueError('PathMasks.batch: single-design masks with one map size expected')
+            ip.append(m.host_indptr[1:] + off)
+            cols.append(m.host_cols)
+            rd.append(np.full(m.num_paths, b, dtype=np.int64))
+            off += int(m.host_cols.shape[0])
+        return PathMasks(np.concatenate(ip), np.concatenate(cols), P, dev, B=len(masks), row_design=np.concatenate(rd))
+
+
+def batch_links(paths, num_paths):
+    """first[q] = first batch row holding path q (-1: none); next[t] = next row with the same path (-1: none)."""
+    paths = np.asarray(paths, dtype=np.int64)
+    T = paths.shape[0]
+    first = np.full(num_paths, -1, dtype=np.int32)
+    nxt = np.full(T, -1, dtype=np.int32)
+    if T:
+        order = np.argsort(paths, kind='stable')
+        sp = paths[order]
+        same = sp[1:] == sp[:-1]
+        nxt[order[:-1][same]] = order[1:][same]
+        starts = np.concatenate([[True], ~same])
+        first[sp[starts]] = order[starts]
+    return first, nxt
 
 
 class MaskedPathMap:
-    """Lazy `index_select(path_masks, 0, paths).to_dense() * feat_map`: rows = `paths`, values from feat_map."""
+    """Lazy `index_select(path_masks, 0, paths).to_dense() * feat_map` (src/train.py:500-501): rows = `paths`
+    (global path ids), values from feat_map [B, P]; never materialised."""
 
-    def __init__(self, masks, paths, feat_map, f_off=None):
+    def __init__(self, masks, paths, feat_map, f_off=None, first=None, next_=None):
         self.masks = masks
-        self.f_off = f_off            # int32 [T]: offset b*P of each row's design into feat_map [B, P] (None = 0)
+        dev = feat_map.device
+        if first is None:                                  # small ad-hoc batches: derive the links on the host
+            ph = paths.detach().cpu().numpy() if torch.is_tensor(paths) else np.asarray(paths)
+            f_h, n_h = batch_links(ph, masks.num_paths)
+            first, next_ = torch.from_numpy(f_h).to(dev), torch.from_numpy(n_h).to(dev)
+            if f_off is None and masks.B > 1:
+                f_off = torch.from_numpy((masks.row_design[ph] * masks.P).astype(np.int32)).to(dev)
         if not torch.is_tensor(paths):
             paths = torch.tensor(paths, dtype=torch.int32)
-        self.paths = paths.to(torch.int32).to(feat_map.device).contiguous()
+        self.paths = paths.to(torch.int32).to(dev).contiguous()
+        self.f_off, self.first, self.next = f_off, first, next_
         self.feat_map = feat_map
-        if feat_map.numel() % masks.P or (f_off is None and feat_map.numel() != masks.P):
-            raise ValueError(f'feat_map has {feat_map.numel()} elements, masks expect (a multiple of) {masks.P}')
+        if feat_map.numel() != masks.B * masks.P:
+            raise ValueError(f'feat_map has {feat_map.numel()} elements, masks expect {masks.B} x {masks.P}')
 
     def __len__(self):
         return self.paths.numel()
@@ -58,39 +107,41 @@ class MaskedPathMap:
 
 class MaskedFcFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat_map, w, b, masks, paths, f_off):
+    def forward(ctx, feat_map, w, b, pm):
         f = feat_map.reshape(-1)
         f = f if f.is_contiguous() else f.contiguous()
         wc = w if w.is_contiguous() else w.contiguous()
         Dout, P = wc.shape
-        T = paths.numel()
+        T = pm.paths.numel()
         dev, st = lib.stream_args(f)
         wT = torch.empty((P, Dout), dtype=torch.float32, device=f.device)
         lib.call('mmft_transpose', wc, wT, Dout, P, dev, st)
         out = torch.empty((T, Dout), dtype=torch.float32, device=f.device)
-        lib.call('mmft_masked_fc_fwd', masks.indptr, masks.cols, paths, f_off, T, f, wT, b, out, P, Dout, dev, st)
-        ctx.masks, ctx.paths, ctx.fshape, ctx.f_off = masks, paths, feat_map.shape, f_off
+        lib.call('mmft_masked_fc_fwd', pm.masks.indptr, pm.masks.cols, pm.paths, pm.f_off, T, f, wT, b, out, P, Dout,
+                 dev, st)
+        ctx.pm, ctx.fshape = pm, feat_map.shape
         ctx.has_bias = b is not None
-        ctx.save_for_backward(f, wc)
+        ctx.save_for_backward(f, wT)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        f, wc = ctx.saved_tensors
-        Dout, P = wc.shape
+        f, wT = ctx.saved_tensors
+        P, Dout = wT.shape
+        pm = ctx.pm
         g = gout if gout.is_contiguous() else gout.contiguous()
-        T = ctx.paths.numel()
         dev, st = lib.stream_args(f)
-        B = f.numel() // P
-        S = torch.zeros((B * P, Dout), dtype=torch.float32, device=f.device)
-        lib.call('mmft_masked_fc_bwd_scatter', ctx.masks.indptr, ctx.masks.cols, ctx.paths, ctx.f_off, T, g, S, P, Dout,
-                 dev, st)
-        dw = torch.empty_like(wc)
+        B = pm.masks.B
+        dwT = torch.empty_like(wT)
         df = torch.empty(B * P, dtype=torch.float32, device=f.device)
-        lib.call('mmft_masked_fc_bwd_finish', S, f, wc, dw, df, B, P, Dout, dev, st)
+        lib.call('mmft_masked_fc_bwd', pm.masks.csc_indptr, pm.masks.csc_paths, pm.first, pm.next, g, f, wT, dwT, df,
+                 B, P, Dout, dev, st)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((Dout, P), dtype=torch.float32, device=f.device)
+            lib.call('mmft_transpose', dwT, dw, P, Dout, dev, st)
         db = ops.colsum(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return (df.reshape(ctx.fshape) if ctx.needs_input_grad[0] else None,
-                dw if ctx.needs_input_grad[1] else None, db, None, None, None)
+        return (df.reshape(ctx.fshape) if ctx.needs_input_grad[0] else None, dw, db, None)
 
 
 def masked_fc(pm, w, b):
@@ -100,7 +151,7 @@ def masked_fc(pm, w, b):
         raise ValueError(f'fcn expects {w.shape[1]} map cells, masks have {pm.masks.P}')
     if w.shape[0] % 4:
         raise ValueError('masked_fc: cnn_outdim must be a multiple of 4')
-    return MaskedFcFn.apply(pm.feat_map, w, b, pm.masks, pm.paths, pm.f_off)
+    return MaskedFcFn.apply(pm.feat_map, w, b, pm)
 
 
 class MseFn(torch.autograd.Function):

@@ -207,3 +207,82 @@ def level_forward(conv, graph, cur_nodes, targets, level_id):
             with torch.no_grad():
                 st.token, out = LevelFn.apply(st.token, st, level_id, rows, tix)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Whole-sweep entry: one autograd node for all L levels.
+#   * the *_self MLPs do not depend on h, so they run ONCE over all nodes of a kind (three batched GEMM
+#     pairs) and pre-fill h; the level-serial chain is then one gather kernel per net level and
+#     gather + two GEMMs per cell level;
+#   * targets are gathered once after the last level (rows are final once written);
+#   * backward = scatter of all target gradients, the reverse pull sweep, batched weight gradients.
+# Same arithmetic as the per-level path (same kernels, same per-row operation order).
+# ------------------------------------------------------------------------------------------------
+class SweepFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, state, level_rows, tix, *params):
+        st, g = state, state.graph
+        P = [_w(p) for p in st.params]
+        (w1c, b1c, w2c, b2c, w1n, b1n, w2n, b2n, w1g, b1g, w2g, b2g) = P
+        act = ops.ACT_RELU if st.relu else ops.ACT_NONE
+        st.levels = [(l, r) for l, r in enumerate(level_rows)]
+        r0 = level_rows[0]
+        rc2 = _cat_rows(st, lambda l: l % 2 == 0 and l > 0)
+        rn = _cat_rows(st, lambda l: l % 2 == 1)
+        st.row_sets = (_cat_rows(st, lambda l: l % 2 == 0), rn, rc2)
+        if r0.numel():                                                                   # level 0, :148-153
+            ops.linear_fwd(st.cell_feat, w1c, b1c, y=st.HS, xidx=r0, yidx=r0, act=ops.ACT_RELU)
+            ops.linear_fwd(st.HS, w2c, b2c, y=st.h, xidx=r0, yidx=r0, act=act)
+        if rc2 is not None:                                                              # fc_cell_self, all cell nodes
+            ops.linear_fwd(st.cell_feat, w1c, b1c, y=st.HS, xidx=rc2, yidx=rc2, act=ops.ACT_RELU)
+            ops.linear_fwd(st.HS, w2c, b2c, y=st.h, xidx=rc2, yidx=rc2)
+        if rn is not None:                                                               # fc_net_self, all net nodes
+            ops.linear_fwd(st.net_feat, w1n, b1n, y=st.HS, xidx=rn, yidx=rn, act=ops.ACT_RELU)
+            ops.linear_fwd(st.HS, w2n, b2n, y=st.h, xidx=rn, yidx=rn)
+        in_net, in_cell = g.csr('in', 'net'), g.csr('in', 'cell')
+        for level_id, rows in enumerate(level_rows):
+            if level_id == 0 or not rows.numel():
+                continue
+            if level_id % 2 == 1:
+                ops.seg_mean_add_act_fwd(st.h, in_net, rows, relu=st.relu)
+            else:
+                ops.seg_softmax_sum_fwd(st.h, in_cell, rows, st.A, st.LSE)
+                ops.linear_fwd(st.A, w1g, b1g, y=st.HN, xidx=rows, yidx=rows, act=ops.ACT_RELU)
+                ops.linear_fwd(st.HN, w2g, b2g, y=st.h, xidx=rows, yidx=rows, epi=ops.EPI_ADD_ACT, act=act)
+        ctx.state, ctx.tix, ctx.nparams = st, tix, len(params)
+        return ops.gather_rows(st.h, tix) if tix.numel() else st.h.new_zeros((0, st.D))
+
+    @staticmethod
+    def backward(ctx, gout):
+        st, g = ctx.state, ctx.state.graph
+        st.bwd_active = False
+        st.begin_backward()
+        if ctx.tix.numel():
+            ops.scatter_add_rows(st.G, ctx.tix, gout if gout.is_contiguous() else gout.contiguous())
+        P = [_w(p) for p in st.params]
+        w1g, w2g = P[8], P[10]
+        out_net, out_cell, in_net_ptr = g.csr('out', 'net'), g.csr('out', 'cell'), g.csr('in', 'net')[0]
+        for level_id, rows in reversed(st.levels):
+            if not rows.numel():
+                continue
+            ops.level_bwd_pull(st.G, st.h, rows, out_net, in_net_ptr, out_cell, st.A, st.LSE, st.DA, relu=st.relu)
+            if level_id % 2 == 0 and level_id > 0:
+                dhn = ops.linear_dgrad(st.G, w2g, gidx=rows, mask=st.HN, maskidx=rows)
+                ops.linear_dgrad(dhn, w1g, dx=st.DA, dxidx=rows)
+        grads = _batched_param_grads(st, P) if ctx.nparams else []
+        st.bwd_active = False
+        return (None, None, None, *grads)
+
+
+def sweep_forward_all(conv, graph, level_nodes, targets):
+    """All levels of one sweep in one call. level_nodes: list (per level) of python int lists or device int32
+    tensors; targets: device int32 tensor (or list) of node ids whose embeddings are returned, in order."""
+    st = SweepState(graph, conv)
+    graph._sweep = st
+    level_rows = [graph.level_rows(l, nodes, 'nodes') for l, nodes in enumerate(level_nodes)]
+    tix = graph.level_rows(-1, targets, 'sweep_targets')
+    st.next_level = len(level_rows)
+    if st.need_grad:
+        return SweepFn.apply(st, level_rows, tix, *st.params)
+    with torch.no_grad():
+        return SweepFn.apply(st, level_rows, tix)

@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from .pingraph import PinGraph
-from .fusion import PathMasks, MaskedPathMap, FlatAdam, mse_loss
+from .fusion import PathMasks, MaskedPathMap, FlatAdam, mse_loss, batch_links
 
 
 def build_models(map_size=128, out_dim=128, cell_feat_dim=36, net_feat_dim=2, cnn_outdim=128, pooling='max',
@@ -86,13 +86,21 @@ class DesignBatch:
         gp, lv = gp[order], lv[order]
         ends = self.path2endpoint[gp]
         counts = np.bincount(lv, minlength=self.L)
-        packed = np.stack([ends, gp, self.path2design[gp] * self.P]).astype(np.int32)
+        first, nxt = batch_links(gp, self.path2level.shape[0])
+        T = gp.shape[0]
+        packed = np.concatenate([ends, gp, self.path2design[gp] * self.P, lv, nxt, first]).astype(np.int32)
         dev = torch.from_numpy(packed).to(self.device)
-        return dev[0], dev[1], dev[2], counts, ends
+        self.links = (dev[5 * T:], dev[4 * T:5 * T])
+        return dev[0:T], dev[T:2 * T], dev[2 * T:3 * T], counts, ends, dev[3 * T:4 * T]
 
 
 class TrainStep:
-    def __init__(self, pmodel, cnn, designs, device, lr=1e-3, weight_decay=0.0, fused_optimizer=True, world_size=1):
+    def __init__(self, pmodel, cnn, designs, device, lr=1e-3, weight_decay=0.0, fused_optimizer=True, world_size=1,
+                 mode='sweep'):
+        """mode='dropin': per-level model() calls exactly as src/train.py:490-511;
+        mode='sweep': PathModel.forward_sweep, same arithmetic with level-invariant work hoisted."""
+        assert mode in ('dropin', 'sweep')
+        self.mode = mode
         self.pmodel, self.cnn = pmodel, cnn
         self.device = torch.device(device)
         self.batch = DesignBatch(designs, device, pmodel.gnn.out_feat_dim if pmodel.gnn is not None else 128)
@@ -113,18 +121,21 @@ class TrainStep:
     # ---------------------------------------------------------------- forward of one mini-batch
     def forward(self, path_ids_per_design):
         b, g = self.batch, self.batch.graph
-        ends_d, paths_d, foff_d, counts, ends_h = b.select(path_ids_per_design)
+        ends_d, paths_d, foff_d, counts, ends_h, lv_d = b.select(path_ids_per_design)
         feat = self.cnn(b.images).reshape(b.B, -1) if self.cnn is not None else None      # src/train.py:465,562
         self.h.zero_()                                                                    # src/train.py:342,559
         g.ndata['h'] = self.h
+        if self.mode == 'sweep':
+            pm = MaskedPathMap(b.masks, paths_d, feat, foff_d if b.B > 1 else None, *b.links) \
+                if feat is not None else None
+            return self.pmodel.forward_sweep(g, b.level_nodes, ends_d, lv_d, pm), ends_d, ends_h
         hats, pos = [], 0
         for level_id in range(b.L):                                                       # src/train.py:490-511
             k = int(counts[level_id])
             targets = ends_d[pos:pos + k]
             path_map = None
             if k and feat is not None:
-                path_map = MaskedPathMap(b.masks, paths_d[pos:pos + k], feat,
-                                         foff_d[pos:pos + k] if b.B > 1 else None)
+                path_map = MaskedPathMap(b.masks, paths_d[pos:pos + k], feat)      # per-level rows: links on the host
             cur = self.pmodel(g, b.level_nodes[level_id], None, targets, level_id, b.level_th[level_id], path_map)
             pos += k
             if cur is not None:

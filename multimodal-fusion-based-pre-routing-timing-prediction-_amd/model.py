@@ -161,3 +161,27 @@ class PathModel(nn.Module):
         else:
             h = th.cat((h_gnn, h_cnn, h_global), 1)
         return self.mlp_fuse(h).squeeze(-1)
+
+    def forward_sweep(self, graph, level_nodes, targets, target_levels, path_map):
+        """Whole-sweep entry: every level of one mini-batch in a single call.
+
+        Equivalent to calling forward() for level 0..L-1 and concatenating the non-None results
+        (src/train.py:490-511), but level-invariant work is hoisted: fcn once over all sampled paths,
+        mlp_alpha once over all level ids, mlp_fuse once over all endpoints, one autograd node for the sweep.
+          level_nodes    list over levels of node-id lists (python ints or device int32 tensors)
+          targets        device int32 tensor [T]: endpoints ordered by level (the order forward() would emit)
+          target_levels  device int32 tensor [T]: level id of each endpoint
+          path_map       MaskedPathMap / dense (T,P) tensor over the same T rows, or None
+        Returns predictions (T,)."""
+        T = len(targets)
+        if T == 0:
+            if self.gnn is not None:
+                _sweep.sweep_forward_all(self.gnn, graph, level_nodes, targets)
+            return None
+        h_cnn = self._fcn(path_map) if (self.fcn is not None and path_map is not None) else None
+        h_gnn = _sweep.sweep_forward_all(self.gnn, graph, level_nodes, targets) if self.gnn is not None else None
+        L = len(level_nodes)
+        lv = th.arange(L, dtype=th.float32, device=targets.device).unsqueeze(1)
+        h_global = MF.gather_rows(self.mlp_alpha(lv), target_levels)          # (T, 32), row = alpha(level of t)
+        parts = [p for p in (h_gnn, h_cnn, h_global) if p is not None]
+        return self.mlp_fuse(th.cat(parts, dim=1)).squeeze(-1)

@@ -293,3 +293,58 @@ def test_flat_adam_matches_torch(dev):
         mine.step()
     for p, q in zip(ps, qs):
         close(q, p, 1e-6, 'adam')
+
+
+@pytest.mark.parametrize('B', [1, 3])
+def test_sweep_entry_equals_dropin(dev, B):
+    """PathModel.forward_sweep (whole-sweep entry) vs the per-level drop-in loop: same predictions and
+    gradients, for one design and for several designs merged block-diagonally (per-image BN statistics)."""
+    from mmft.synth import synth_design
+    from mmft.train import build_models, TrainStep
+    from mmft.fusion import mse_loss
+    designs = [synth_design(N=2048, L=12, tile=32, seed=100 + i, end_frac=0.25) for i in range(B)]
+    rng = np.random.default_rng(5)
+    ids = [rng.permutation(d.num_paths)[:40].tolist() + [0, 0] for d in designs]      # with duplicates
+    res = {}
+    for mode in ('dropin', 'sweep'):
+        pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=7)
+        ts = TrainStep(pmodel, cnn, designs, dev, mode=mode)
+        hats, ends_d, ends_h = ts.forward(ids)
+        loss = mse_loss(hats, ts.batch.arrival[ends_d.long()].squeeze(-1))
+        ts.optim.zero_grad()
+        loss.backward()
+        grads = {k: p.grad.clone() for k, p in list(pmodel.named_parameters()) + [('cnn.' + a, b) for a, b in cnn.named_parameters()]
+                 if p.grad is not None}
+        res[mode] = (hats.detach().clone(), grads, ts.h.clone())
+    close(res['sweep'][0], res['dropin'][0], 1e-5, 'hats')
+    close(res['sweep'][2], res['dropin'][2], 1e-5, 'h')
+    assert set(res['sweep'][1]) == set(res['dropin'][1])
+    for k in res['dropin'][1]:
+        close(res['sweep'][1][k], res['dropin'][1][k], 5e-5, 'grad ' + k)
+
+
+def test_batched_designs_equal_single(dev):
+    """Merging designs block-diagonally (per-image BatchNorm statistics) gives every design the predictions it
+    gets when stepped alone, as the reference does (one design at a time)."""
+    from mmft.synth import synth_design
+    from mmft.train import build_models, TrainStep
+    designs = [synth_design(N=2048, L=12, tile=32, seed=200 + i, end_frac=0.25) for i in range(3)]
+    rng = np.random.default_rng(6)
+    ids = [rng.permutation(d.num_paths)[:30].tolist() for d in designs]
+    pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=7)
+    sd_m = {k: v.clone() for k, v in pmodel.state_dict().items()}
+    sd_c = {k: v.clone() for k, v in cnn.state_dict().items()}
+    ts = TrainStep(pmodel, cnn, designs, dev)
+    with torch.no_grad():
+        hats_all, ends_d, ends_h = ts.forward(ids)
+    for i, d in enumerate(designs):
+        pm_i, cnn_i = build_models(map_size=d.map_size, device=dev, seed=7)
+        pm_i.load_state_dict(sd_m); cnn_i.load_state_dict(sd_c)
+        t1 = TrainStep(pm_i, cnn_i, [d], dev)
+        with torch.no_grad():
+            h1, e1, eh1 = t1.forward([ids[i]])
+        # rows of design i inside the merged batch: endpoints in [node_off[i], node_off[i+1])
+        lo, hi = ts.batch.node_off[i], ts.batch.node_off[i + 1]
+        sel = torch.from_numpy(((ends_h >= lo) & (ends_h < hi))).to(dev)
+        assert (ends_h[(ends_h >= lo) & (ends_h < hi)] - lo).tolist() == eh1.tolist()
+        close(hats_all[sel], h1, 2e-5, f'design {i}')
