@@ -74,35 +74,52 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const float* __restrict
   }
 }
 
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ partial,
-                                                          int groups, long long rows, int C, int blocks_per_group,
-                                                          float eps, float momentum, float* __restrict__ running_mean,
-                                                          float* __restrict__ running_var, float* __restrict__ save_mean,
-                                                          float* __restrict__ save_invstd) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double rm = running_mean ? (double)running_mean[c] : 0.0, rv = running_var ? (double)running_var[c] : 0.0;
-  for (int g = 0; g < groups; ++g) {
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < blocks_per_group; ++b) {
-      const float* q = partial + ((long long)(g * blocks_per_group + b) * 2) * C;
-      s += (double)q[c];
-      ss += (double)q[C + c];
-    }
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// stage 2: one wave per (group, channel) combines the row-block partials in fp64
+__global__ void __launch_bounds__(64) bn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ partial,
+                                                         long long rows, int C, int blocks_per_group, float eps,
+                                                         float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                         float* __restrict__ save_var) {
+  int g = blockIdx.x / C, c = blockIdx.x % C;
+  double s = 0.0, ss = 0.0;
+  for (int b = threadIdx.x; b < blocks_per_group; b += 64) {
+    const float* q = partial + ((long long)(g * blocks_per_group + b) * 2) * C;
+    s += (double)q[c];
+    ss += (double)q[C + c];
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  if (threadIdx.x == 0) {
     double shift = (double)x[(long long)g * rows * C + c];
     double n = (double)rows;
     double m_sh = s / n;
     double var = ss / n - m_sh * m_sh;
     if (var < 0.0) var = 0.0;
-    double mean = m_sh + shift;
-    save_mean[g * C + c] = (float)mean;
+    save_mean[g * C + c] = (float)(m_sh + shift);
     save_invstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    save_var[g * C + c] = (float)var;
+  }
+}
+
+// running statistics: `groups` sequential momentum updates per channel (one per image when per-sample)
+__global__ void __launch_bounds__(256) bn_running_kernel(const float* __restrict__ save_mean, const float* __restrict__ save_var,
+                                                         int groups, long long rows, int C, float momentum,
+                                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double rm = (double)running_mean[c], rv = (double)running_var[c], n = (double)rows;
+  for (int g = 0; g < groups; ++g) {
+    double var = (double)save_var[g * C + c];
     double unbiased = rows > 1 ? var * n / (n - 1.0) : var;
-    rm = (1.0 - (double)momentum) * rm + (double)momentum * mean;      // sequential updates, one per group
+    rm = (1.0 - (double)momentum) * rm + (double)momentum * (double)save_mean[g * C + c];
     rv = (1.0 - (double)momentum) * rv + (double)momentum * unbiased;
   }
-  if (running_mean) running_mean[c] = (float)rm;
-  if (running_var) running_var[c] = (float)rv;
+  running_mean[c] = (float)rm;
+  running_var[c] = (float)rv;
 }
 
 __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -159,27 +176,35 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __rest
   }
 }
 
-// stage 2: per-group means (coef[g][0..1][C]) and dgamma/dbeta summed over groups
-__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ partial, int groups, long long rows,
-                                                              int C, int blocks_per_group, float* __restrict__ coef,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+// stage 2: one wave per (group, channel): per-group means coef[g][0..1][C]; then dgamma/dbeta over groups
+__global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const float* __restrict__ partial, long long rows, int C,
+                                                             int blocks_per_group, float* __restrict__ coef) {
+  int g = blockIdx.x / C, c = blockIdx.x % C;
+  double s = 0.0, sx = 0.0;
+  for (int b = threadIdx.x; b < blocks_per_group; b += 64) {
+    const float* q = partial + ((long long)(g * blocks_per_group + b) * 2) * C;
+    s += (double)q[c];
+    sx += (double)q[C + c];
+  }
+  s = wave_sum(s);
+  sx = wave_sum(sx);
+  if (threadIdx.x == 0) {
+    coef[(g * 2) * C + c] = (float)(s / (double)rows);
+    coef[(g * 2 + 1) * C + c] = (float)(sx / (double)rows);
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_params_kernel(const float* __restrict__ coef, int groups, long long rows, int C,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double dg = 0.0, db = 0.0;
   for (int g = 0; g < groups; ++g) {
-    double s = 0.0, sx = 0.0;
-    for (int b = 0; b < blocks_per_group; ++b) {
-      const float* q = partial + ((long long)(g * blocks_per_group + b) * 2) * C;
-      s += (double)q[c];
-      sx += (double)q[C + c];
-    }
-    coef[(g * 2) * C + c] = (float)(s / (double)rows);
-    coef[(g * 2 + 1) * C + c] = (float)(sx / (double)rows);
-    db += s;
-    dg += sx;
+    db += (double)coef[(g * 2) * C + c];
+    dg += (double)coef[(g * 2 + 1) * C + c];
   }
-  dgamma[c] = (float)dg;
-  dbeta[c] = (float)db;
+  dgamma[c] = (float)(dg * (double)rows);
+  dbeta[c] = (float)(db * (double)rows);
 }
 
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ x,
@@ -410,10 +435,14 @@ int mmft_bn_train_fwd(const float* x, float* y, const float* gamma, const float*
   DeviceGuard dg(device);
   hipStream_t st = (hipStream_t)stream;
   int bpg = bn_blocks(rows);
-  ProfScope ps("bn_train_fwd(3 kernels)", 0.0, 3.0 * 4.0 * groups * rows * C, st);
+  ProfScope ps("bn_train_fwd(4 kernels)", 0.0, 3.0 * 4.0 * groups * rows * C, st);
   hipLaunchKernelGGL(bn_partial_kernel, dim3(groups * bpg), dim3(256), 0, st, x, rows, C, bpg, workspace);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, x, workspace, groups, rows, C, bpg, eps,
-                     momentum, running_mean, running_var, save_mean, save_invstd);
+  float* save_var = workspace + (long long)groups * bpg * 2 * C;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(groups * C), dim3(64), 0, st, x, workspace, rows, C, bpg, eps, save_mean,
+                     save_invstd, save_var);
+  if (running_mean && running_var)
+    hipLaunchKernelGGL(bn_running_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, save_mean, save_var, groups, rows, C,
+                       momentum, running_mean, running_var);
   long long total = (long long)groups * rows * C;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y, gamma, beta, save_mean, save_invstd,
                      rows, C, total, relu);
@@ -431,11 +460,11 @@ int mmft_bn_train_bwd(const float* gy, const float* x, const float* y, const flo
   hipStream_t st = (hipStream_t)stream;
   int bpg = bn_blocks(rows);
   float* coef = workspace + (long long)groups * bpg * 2 * C;
-  ProfScope ps("bn_train_bwd(3 kernels)", 0.0, 7.0 * 4.0 * groups * rows * C, st);
+  ProfScope ps("bn_train_bwd(4 kernels)", 0.0, 7.0 * 4.0 * groups * rows * C, st);
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(groups * bpg), dim3(256), 0, st, gy, x, y, save_mean, save_invstd, rows, C,
                      bpg, relu, workspace);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, workspace, groups, rows, C, bpg, coef,
-                     dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(groups * C), dim3(64), 0, st, workspace, rows, C, bpg, coef);
+  hipLaunchKernelGGL(bn_bwd_params_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, coef, groups, rows, C, dgamma, dbeta);
   long long total = (long long)groups * rows * C;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, gy, x, y, gamma, save_mean, save_invstd,
                      coef, dx, rows, C, total, relu);

@@ -454,27 +454,34 @@ inline int effective_splits(int K, int splits) {
   return (K + ksplit - 1) / ksplit;
 }
 
-// Tile choice: features first (BN = smallest of 16/32/64/128 covering N, capped at 128), then the
-// row tile so that the grid has at least ~1 workgroup per CU (256 CUs) when the problem allows.
+// Tile choice: features first (BN = smallest of 16/32/64/128 covering N, capped at 128), then the largest row
+// tile that (a) does not exceed M rounded up to 16 - so that Co = 16/32 weight-gradient GEMMs are not padded to
+// 128 rows of wasted MFMA work - and (b) still gives the grid at least ~1 workgroup per CU (256 CUs).
 template <class XL, class WL>
 inline int launch_gemm(const XL& xl, const WL& wl, const Epi& epi, int M, int N, int K, int splits, hipStream_t st) {
   if (M <= 0 || N <= 0) return MMFT_OK;
-  auto tiles = [&](int bm, int bn) { return (long long)cdiv(M, bm) * cdiv(N, bn) * (splits > 1 ? splits : 1); };
+  const int sp = splits > 1 ? splits : 1;
+  const int mcap = ((M + 15) / 16) * 16;
+  auto ok = [&](int bm, int bn) { return bm <= mcap && (long long)cdiv(M, bm) * cdiv(N, bn) * sp >= 256; };
+#define MMFT_GO(BM, BN, WM, WN) launch_cfg<TileCfg<BM, BN, 16, WM, WN>>(xl, wl, epi, M, N, K, splits, st)
   if (N <= 16) {
-    if (tiles(128, 16) >= 256) launch_cfg<TileCfg<128, 16, 16, 4, 1>>(xl, wl, epi, M, N, K, splits, st);
-    else launch_cfg<TileCfg<64, 16, 16, 4, 1>>(xl, wl, epi, M, N, K, splits, st);
+    if (ok(128, 16)) MMFT_GO(128, 16, 4, 1);
+    else MMFT_GO(64, 16, 4, 1);
   } else if (N <= 32) {
-    if (tiles(128, 32) >= 256) launch_cfg<TileCfg<128, 32, 16, 4, 1>>(xl, wl, epi, M, N, K, splits, st);
-    else launch_cfg<TileCfg<64, 32, 16, 4, 1>>(xl, wl, epi, M, N, K, splits, st);
+    if (ok(128, 32)) MMFT_GO(128, 32, 4, 1);
+    else MMFT_GO(64, 32, 4, 1);
   } else if (N <= 64) {
-    if (tiles(128, 64) >= 256) launch_cfg<TileCfg<128, 64, 16, 2, 2>>(xl, wl, epi, M, N, K, splits, st);
-    else if (tiles(64, 64) >= 256) launch_cfg<TileCfg<64, 64, 16, 2, 2>>(xl, wl, epi, M, N, K, splits, st);
-    else launch_cfg<TileCfg<32, 64, 16, 2, 2>>(xl, wl, epi, M, N, K, splits, st);
+    if (ok(128, 64)) MMFT_GO(128, 64, 2, 2);
+    else if (ok(64, 64)) MMFT_GO(64, 64, 2, 2);
+    else if (mcap >= 32) MMFT_GO(32, 64, 2, 2);
+    else MMFT_GO(16, 64, 1, 4);
   } else {
-    if (tiles(128, 128) >= 256) launch_cfg<TileCfg<128, 128, 16, 2, 2>>(xl, wl, epi, M, N, K, splits, st);
-    else if (tiles(64, 128) >= 256) launch_cfg<TileCfg<64, 128, 16, 2, 2>>(xl, wl, epi, M, N, K, splits, st);
-    else launch_cfg<TileCfg<32, 128, 16, 2, 2>>(xl, wl, epi, M, N, K, splits, st);
+    if (ok(128, 128)) MMFT_GO(128, 128, 2, 2);
+    else if (ok(64, 128)) MMFT_GO(64, 128, 2, 2);
+    else if (mcap >= 32) MMFT_GO(32, 128, 2, 2);
+    else MMFT_GO(16, 128, 1, 4);
   }
+#undef MMFT_GO
   return check_launch("gemm_f32");
 }
 

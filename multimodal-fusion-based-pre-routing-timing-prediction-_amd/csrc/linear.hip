@@ -55,45 +55,98 @@ void prof_end(hipStream_t st) {
 }
 
 // ---------------------------------------------------------------- split-K slab combine
+// out[i] = (accumulate ? out[i] : 0) + sum_z slab[z][i].  256 threads = 16 slab lanes x 16 column groups of
+// VEC elements: every thread sums its share of the slabs with independent loads (latency overlaps), the 16
+// partials are combined through LDS in a fixed order -> bitwise reproducible for a given split count.
+template <int VEC>
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, int splits, long long elems,
                                                           float* __restrict__ out, int accumulate) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  long long stride = (long long)gridDim.x * blockDim.x;
-  for (; i < elems; i += stride) {
-    float s = accumulate ? out[i] : 0.f;
-    for (int z = 0; z < splits; ++z) s += slabs[(long long)z * elems + i];
-    out[i] = s;
+  __shared__ float part[16][16 * VEC + 1];
+  const int zl = threadIdx.x >> 4, cg = threadIdx.x & 15;
+  const long long i0 = ((long long)blockIdx.x * 16 + cg) * VEC;
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  if (i0 < elems) {
+    for (int z = zl; z < splits; z += 16) {
+      const float* q = slabs + (long long)z * elems + i0;
+      if (VEC == 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(q);
+        acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+      } else {
+        acc[0] += q[0];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) part[zl][cg * VEC + j] = acc[j];
+  __syncthreads();
+  if (threadIdx.x < 16 * VEC) {
+    long long i = (long long)blockIdx.x * 16 * VEC + threadIdx.x;
+    if (i < elems) {
+      float s = accumulate ? out[i] : 0.f;
+#pragma unroll
+      for (int z = 0; z < 16; ++z) s += part[z][threadIdx.x];
+      out[i] = s;
+    }
   }
 }
 
 int launch_slab_reduce(const float* slabs, int splits, long long elems, float* out, int accumulate, hipStream_t st) {
   ProfScope ps("slab_reduce_kernel", 0.0, 4.0 * (splits + 1.0) * elems, st);
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ew_grid(elems)), dim3(256), 0, st, slabs, splits, elems, out, accumulate);
+  if (elems % 4 == 0 && aligned16(slabs)) {
+    hipLaunchKernelGGL(slab_reduce_kernel<4>, dim3(cdiv(elems, 64)), dim3(256), 0, st, slabs, splits, elems, out, accumulate);
+  } else {
+    hipLaunchKernelGGL(slab_reduce_kernel<1>, dim3(cdiv(elems, 16)), dim3(256), 0, st, slabs, splits, elems, out, accumulate);
+  }
   return check_launch("slab_reduce");
 }
 
 // ---------------------------------------------------------------- column sums (bias gradients)
-// stage 1: each block sums a strip of rows into partial[block][cols]; stage 2 = slab_reduce (fixed order)
+// stage 1: block = 16 row lanes x 16 column groups (4 columns each) over a strip of rows -> partial[strip][cols];
+// stage 2 = slab_reduce (fixed order)
+constexpr int COLSUM_STRIP = 1024;
 __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ g, const int* __restrict__ idx,
-                                                             long long ld, int rows, int cols, int rows_per_block,
+                                                             long long ld, int rows, int cols,
                                                              float* __restrict__ partial) {
-  int r0 = blockIdx.x * rows_per_block;
-  int r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) {
+  __shared__ float part[16][65];
+  const int rl = threadIdx.x >> 4, cg = threadIdx.x & 15;
+  const int c0 = blockIdx.x * 64 + cg * 4;
+  const int r0 = blockIdx.y * COLSUM_STRIP;
+  const int r1 = r0 + COLSUM_STRIP < rows ? r0 + COLSUM_STRIP : rows;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool vec = (ld % 4 == 0) && (c0 + 3 < cols) && ((reinterpret_cast<uintptr_t>(g) & 15) == 0);
+  if (c0 < cols) {
+    for (int r = r0 + rl; r < r1; r += 16) {
       long long rr = idx ? (long long)idx[r] : (long long)r;
-      s += g[rr * ld + c];
+      const float* q = g + rr * ld + c0;
+      if (vec) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(q);
+        acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c0 + j < cols) acc[j] += q[j];
+      }
     }
-    partial[(long long)blockIdx.x * cols + c] = s;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) part[rl][cg * 4 + j] = acc[j];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < cols) {
+      float s = 0.f;
+#pragma unroll
+      for (int z = 0; z < 16; ++z) s += part[z][threadIdx.x];
+      partial[(long long)blockIdx.y * cols + c] = s;
+    }
   }
 }
 
 static inline int colsum_blocks(int rows) {
-  int nb = cdiv(rows, 64);
-  if (nb > 1024) nb = 1024;
-  if (nb < 1) nb = 1;
-  return nb;
+  int nb = cdiv(rows, COLSUM_STRIP);
+  return nb < 1 ? 1 : nb;
 }
 
 __global__ void __launch_bounds__(256) act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
@@ -269,11 +322,9 @@ int mmft_colsum(const float* g, const int* idx, long long ld, int rows, int cols
   }
   int nb = colsum_blocks(rows);
   MMFT_REQUIRE(workspace && workspace_bytes >= (long long)nb * cols * 4, "colsum: workspace too small");
-  int rpb = cdiv(rows, nb);
-  nb = cdiv(rows, rpb);
   {
     ProfScope ps("colsum_partial_kernel", 0.0, 4.0 * rows * cols, st);   // scoped: slab_reduce below has its own
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, g, idx, ld, rows, cols, rpb, workspace);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(cols, 64), nb), dim3(256), 0, st, g, idx, ld, rows, cols, workspace);
   }
   int rc = check_launch("colsum_partial");
   if (rc) return rc;
