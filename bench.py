@@ -112,8 +112,9 @@ def main():
     from mmft.train import build_models, TrainStep
     from mmft import lib
 
-    designs = [synth_design(N=args.nodes, L=args.levels, tile=args.tile, seed=9294 + rank * args.designs + i)
-               for i in range(args.designs)]
+    from mmft.dist import design_seeds
+    designs = [synth_design(N=args.nodes, L=args.levels, tile=args.tile, seed=sd)
+               for sd in design_seeds(rank, args.designs)]
     log(f'rank {rank}: {len(designs)} designs generated')
     pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=9294)
     pm_state = {k: v.detach().cpu().clone() for k, v in pmodel.state_dict().items()}

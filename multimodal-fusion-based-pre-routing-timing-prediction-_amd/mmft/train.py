@@ -151,9 +151,8 @@ class TrainStep:
         self.optim.zero_grad()
         loss.backward()
         if self.world_size > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.optim.flat_grad)
-            self.optim.step(gscale=1.0 / self.world_size)
+            from .dist import allreduce_sum_
+            self.optim.step(gscale=allreduce_sum_(self.optim.flat_grad, self.world_size))
         else:
             self.optim.step()
         return loss.detach(), hats.detach(), ends_h.tolist()

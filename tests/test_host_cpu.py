@@ -1,0 +1,133 @@
+"""CPU: host-side logic (synthetic designs, PinGraph, batch bookkeeping), the C ABI's load/export/error
+behaviour without a GPU, and the 'fails loudly' contract of the product path."""
+import ctypes
+import numpy as np
+import pytest
+import torch
+
+from mmft import lib
+from mmft.synth import synth_design
+from mmft.pingraph import PinGraph
+from mmft.fusion import batch_links, PathMasks
+
+
+def test_library_exports_every_declared_symbol():
+    L = lib.load()
+    names = lib.header_symbols()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(L, n), f'{n} declared in include/mmft.h but not exported'
+    assert L.mmft_version() >= 100
+
+
+def test_c_abi_reports_errors_without_touching_the_gpu():
+    L = lib.load()
+    rc = L.mmft_linear_fwd(None, None, 0, None, 0, None, None, None, 0, 4, 4, 4, 0, 0, 0.0, 0, None)
+    assert rc == -1 and b'null pointer' in L.mmft_last_error()
+    rc = L.mmft_gather_rows(None, 4, None, 0, 6, None, 4, 0, None)        # D not a multiple of 4
+    assert rc == -1 and b'multiple of 4' in L.mmft_last_error()
+    assert L.mmft_conv2d_wgrad_workspace_bytes(8, 256, 256, 16, 16, 3, 3) > 0
+
+
+def test_product_path_refuses_cpu_tensors():
+    import model
+    net = model.MLP(4, 8, 2)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        net(torch.zeros(3, 4))
+    import Unet
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        Unet.UNet('max')(torch.zeros(1, 3, 16, 16))
+
+
+def test_state_dict_keys_match_reference_names():
+    import model, Unet
+    u = Unet.UNet('max')
+    keys = set(u.state_dict().keys())
+    for k in ('inc.double_conv.0.weight', 'inc.double_conv.1.running_mean', 'down3.maxpool_conv.1.double_conv.4.bias',
+              'up1.up.weight', 'up2.conv.double_conv.3.weight', 'outc.conv.0.bias',
+              'inc.double_conv.4.num_batches_tracked'):
+        assert k in keys
+    assert sum(p.numel() for p in u.parameters()) == 482737
+    assert tuple(u.up1.up.weight.shape) == (128, 64, 2, 2)
+    g = model.PathConv(128, 128, 36, 2)
+    assert sum(p.numel() for p in g.parameters()) == 142464
+    pm = model.PathModel(g, None, torch.nn.Linear(16384, 128), None, None, model.MLP(288, 576, 1))
+    for k in ('gnn.fc_cell_neigh.layers.0.weight', 'gnn.fc_net_drive.layers.0.bias', 'gnn.fc_attn2.weight', 'fcn.weight',
+              'mlp_fuse.layers.2.bias', 'mlp_alpha.layers.0.weight'):
+        assert k in pm.state_dict()
+    assert sum(p.numel() for p in model.LayoutNet('max').parameters()) == 273121
+    import pickle
+    pickle.loads(pickle.dumps((pm, u)))                                           # whole-object pickling, src/train.py:86-91
+
+
+def test_synth_invariants():
+    d = synth_design(N=4096, L=16, tile=64, seed=1)
+    level_of = np.full(d.N, -1)
+    for l, nodes in enumerate(d.levels):
+        level_of[nodes] = l
+    assert (level_of >= 0).all() and sum(len(x) for x in d.levels) == d.N
+    # net edges: odd destination, exactly one driver, driver exactly one level below
+    assert (level_of[d.net_dst] % 2 == 1).all() and (level_of[d.net_src] == level_of[d.net_dst] - 1).all()
+    assert (np.bincount(d.net_dst, minlength=d.N)[level_of % 2 == 1] == 1).all()
+    # cell edges: even destination >= 2, sources on earlier odd levels, at least one exactly one level below
+    assert (level_of[d.cell_dst] % 2 == 0).all() and (level_of[d.cell_dst] >= 2).all()
+    assert (level_of[d.cell_src] % 2 == 1).all() and (level_of[d.cell_src] < level_of[d.cell_dst]).all()
+    best = np.full(d.N, -1)
+    np.maximum.at(best, d.cell_dst, level_of[d.cell_src])
+    sel = (level_of % 2 == 0) & (level_of >= 2)
+    assert (best[sel] == level_of[sel] - 1).all()
+    # endpoints and masks
+    assert (level_of[d.path2endpoint] == d.path2level).all()
+    assert d.mask_cols.max() < d.map_size ** 2 and (np.diff(d.mask_indptr) > 0).all()
+    tl = d.topo_levels()
+    assert len(tl) == d.L and all(len(t) == 3 and isinstance(t[0], list) for t in tl)
+    assert d.cell_feat.shape == (d.N, 36) and d.net_feat.shape == (d.N, 2) and d.image.shape == (3, 64, 64)
+
+
+def test_pingraph_csr_and_surface():
+    src = np.array([0, 1, 1, 2, 0]); dst = np.array([3, 3, 4, 4, 4])
+    g = PinGraph(5, {'net': (src, dst), 'cell': ((), ())})
+    ip, ix = g.csr_host('in', 'net')
+    assert ip.tolist() == [0, 0, 0, 0, 2, 5] and ix.tolist() == [0, 1, 1, 2, 0]       # insertion order kept
+    op, ox = g.csr_host('out', 'net')
+    assert op.tolist() == [0, 2, 4, 5, 5, 5] and ox.tolist() == [3, 4, 3, 4, 4]
+    g.ndata['h'] = torch.zeros(5, 4)
+    assert g.nodes['pin'].data['h'] is g.ndata['h']
+    assert g.number_of_nodes() == 5 and g.number_of_edges(etype='net') == 5 and g.number_of_edges(etype='cell') == 0
+    nodes = [4, 3]
+    a = g.level_rows(1, nodes)
+    assert g.level_rows(1, nodes) is a and a.dtype == torch.int32 and a.tolist() == [4, 3]
+    assert g.level_rows(1, [3, 4]) is not a
+    with pytest.raises(AssertionError):
+        g.level_rows(2, [7])
+    g2 = PinGraph.batch([g, g])
+    assert g2.number_of_nodes() == 10 and g2.csr_host('in', 'net')[1].tolist() == [0, 1, 1, 2, 0, 5, 6, 6, 7, 5]
+    assert g2.ndata['h'].shape == (10, 4)
+
+
+def test_batch_links_and_transposed_masks():
+    first, nxt = batch_links([3, 1, 3, 0, 3, 1], 5)
+    assert first.tolist() == [3, 1, -1, 0, -1] and nxt.tolist() == [2, 5, 4, -1, -1, -1]
+    f0, n0 = batch_links([], 3)
+    assert f0.tolist() == [-1, -1, -1] and n0.shape == (0,)
+    m = PathMasks([0, 2, 3, 5], [1, 3, 3, 0, 1], 4, 'cpu')
+    assert m.csc_indptr.tolist() == [0, 1, 3, 3, 5] and m.csc_paths.tolist() == [2, 0, 2, 0, 1]
+    mb = PathMasks.batch([m, m])
+    assert mb.B == 2 and mb.num_paths == 6 and mb.csc_indptr.numel() == 9
+    assert mb.csc_paths.tolist() == [2, 0, 2, 0, 1, 5, 3, 5, 3, 4]
+
+
+def test_design_batch_select_order():
+    from mmft.train import DesignBatch
+    ds = [synth_design(N=512, L=8, tile=16, seed=10 + i, end_frac=0.5) for i in range(2)]
+    b = DesignBatch(ds, 'cpu')
+    ids = [[5, 0, 7, 0], [1, 3]]
+    ends, paths, foff, counts, ends_h, lv = b.select(ids)
+    # ordered by level, then design, then appearance (src/train.py:476-484 for B = 1)
+    exp = sorted([(int(ds[i].path2level[p]), i, k, p) for i, row in enumerate(ids) for k, p in enumerate(row)])
+    assert paths.tolist() == [int(p + b.path_off[i]) for (_, i, _, p) in exp]
+    assert ends.tolist() == [int(ds[i].path2endpoint[p] + b.node_off[i]) for (_, i, _, p) in exp]
+    assert foff.tolist() == [i * b.P for (_, i, _, _) in exp] and lv.tolist() == [l for (l, _, _, _) in exp]
+    assert counts.sum() == 6 and len(b.level_nodes) == 8
+    first, nxt = b.links
+    assert first.numel() == b.path_off[-1] and nxt.numel() == 6
