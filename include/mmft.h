@@ -91,14 +91,15 @@ int mmft_seg_mean_add_act_fwd(float* h, long long ldh, const int* in_indptr, con
 /* out[v] = mean_{u->v} src[u]  (standalone fn.mean) */
 int mmft_seg_mean_fwd(const float* src, long long lds, const int* in_indptr, const int* in_indices,
                       const int* rows, int n, int D, float* out, long long ldo, int device, void* stream);
-/* Reverse sweep, one level (deterministic pull over out-edges, no atomics):
- *   gh = G[v] + sum_{w in out_net(v)} G[w]/indeg_net(w)
+/* Reverse sweep, one level (deterministic pull over out-edges, no atomics); out_net_weight[e] = 1/indeg_net of
+ * the destination of out-edge e (static per graph, aligned with out_net_indices):
+ *   gh = G[v] + sum_{e: v->w in out_net(v)} G[w] * out_net_weight[e]
  *             + sum_{w in out_cell(v)} DA[w] * exp(h[v]-LSE[w]) * (1 + h[v] - A[w])
  *   G[v] = relu ? (h[v] > 0 ? gh : 0) : gh
  * G rows of later levels hold d(loss)/d(pre-activation), DA rows d(loss)/d(A); both must be zero for
  * nodes whose backward has not run. */
 int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows, int n, int D,
-                        const int* out_net_indptr, const int* out_net_indices, const int* in_net_indptr,
+                        const int* out_net_indptr, const int* out_net_indices, const float* out_net_weight,
                         const int* out_cell_indptr, const int* out_cell_indices,
                         const float* A, const float* LSE, const float* DA, int relu,
                         int device, void* stream);

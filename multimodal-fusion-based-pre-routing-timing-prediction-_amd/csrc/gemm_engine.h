@@ -454,32 +454,57 @@ inline int effective_splits(int K, int splits) {
   return (K + ksplit - 1) / ksplit;
 }
 
-// Tile choice: features first (BN = smallest of 16/32/64/128 covering N, capped at 128), then the largest row
-// tile that (a) does not exceed M rounded up to 16 - so that Co = 16/32 weight-gradient GEMMs are not padded to
-// 128 rows of wasted MFMA work - and (b) still gives the grid at least ~1 workgroup per CU (256 CUs).
+// Tile choice.  Candidates are ordered by tile area; the first one that (a) does not exceed M / N rounded up to 16
+// (Co = 16/32 weight-gradient GEMMs must not be padded to 128 rows of wasted MFMA work) and (b) still fills the
+// chip is taken.  "Fills" is tried at >= 1024, then 512, then 256 workgroups (256 CUs): the level-serial GEMMs of
+// the sweep (M ~ 1k-8k rows, K = 128/256) are latency-bound at 8 K-steps per tile, so thread-level parallelism
+// (4 workgroups per CU) hides what a short K loop cannot.
 template <class XL, class WL>
 inline int launch_gemm(const XL& xl, const WL& wl, const Epi& epi, int M, int N, int K, int splits, hipStream_t st) {
   if (M <= 0 || N <= 0) return MMFT_OK;
   const int sp = splits > 1 ? splits : 1;
-  const int mcap = ((M + 15) / 16) * 16;
-  auto ok = [&](int bm, int bn) { return bm <= mcap && (long long)cdiv(M, bm) * cdiv(N, bn) * sp >= 256; };
+  const int mcap = ((M + 15) / 16) * 16, ncap = ((N + 15) / 16) * 16;
+  static const int cand[][2] = {{128, 128}, {64, 128}, {128, 64}, {32, 128}, {64, 64}, {128, 32}, {32, 64},
+                                {16, 128}, {64, 32}, {128, 16}, {16, 64}, {64, 16}};
+  const int ncand = sizeof(cand) / sizeof(cand[0]);
+  auto fits = [&](int i) {
+    int bm = cand[i][0], bn = cand[i][1];
+    if (bn > ncap && bn != 16) return false;            // do not pad features beyond the next multiple of 16...
+    if (bm > mcap && bm != 16 && !(bm == 64 && bn <= 32)) return false;   // ...nor rows (smallest shapes excepted)
+    return true;
+  };
+  auto wgs = [&](int i) { return (long long)cdiv(M, cand[i][0]) * cdiv(N, cand[i][1]) * sp; };
+  int pick = -1;
+  const long long want[3] = {1024, 512, 256};
+  for (int t = 0; t < 3 && pick < 0; ++t)
+    for (int i = 0; i < ncand; ++i)
+      if (fits(i) && wgs(i) >= want[t]) {
+        pick = i;
+        break;
+      }
+  if (pick < 0) {                                         // tiny problem: the fitting candidate with most workgroups
+    long long best = -1;
+    for (int i = 0; i < ncand; ++i)
+      if (fits(i) && wgs(i) > best) {
+        best = wgs(i);
+        pick = i;
+      }
+  }
+  if (pick < 0) pick = ncand - 1;
 #define MMFT_GO(BM, BN, WM, WN) launch_cfg<TileCfg<BM, BN, 16, WM, WN>>(xl, wl, epi, M, N, K, splits, st)
-  if (N <= 16) {
-    if (ok(128, 16)) MMFT_GO(128, 16, 4, 1);
-    else MMFT_GO(64, 16, 4, 1);
-  } else if (N <= 32) {
-    if (ok(128, 32)) MMFT_GO(128, 32, 4, 1);
-    else MMFT_GO(64, 32, 4, 1);
-  } else if (N <= 64) {
-    if (ok(128, 64)) MMFT_GO(128, 64, 2, 2);
-    else if (ok(64, 64)) MMFT_GO(64, 64, 2, 2);
-    else if (mcap >= 32) MMFT_GO(32, 64, 2, 2);
-    else MMFT_GO(16, 64, 1, 4);
-  } else {
-    if (ok(128, 128)) MMFT_GO(128, 128, 2, 2);
-    else if (ok(64, 128)) MMFT_GO(64, 128, 2, 2);
-    else if (mcap >= 32) MMFT_GO(32, 128, 2, 2);
-    else MMFT_GO(16, 128, 1, 4);
+  switch (cand[pick][0] * 1000 + cand[pick][1]) {
+    case 128128: MMFT_GO(128, 128, 2, 2); break;
+    case 64128: MMFT_GO(64, 128, 2, 2); break;
+    case 128064: MMFT_GO(128, 64, 2, 2); break;
+    case 32128: MMFT_GO(32, 128, 2, 2); break;
+    case 64064: MMFT_GO(64, 64, 2, 2); break;
+    case 128032: MMFT_GO(128, 32, 4, 1); break;
+    case 32064: MMFT_GO(32, 64, 2, 2); break;
+    case 16128: MMFT_GO(16, 128, 1, 4); break;
+    case 64032: MMFT_GO(64, 32, 4, 1); break;
+    case 128016: MMFT_GO(128, 16, 4, 1); break;
+    case 16064: MMFT_GO(16, 64, 1, 4); break;
+    default: MMFT_GO(64, 16, 4, 1); break;
   }
 #undef MMFT_GO
   return check_launch("gemm_f32");

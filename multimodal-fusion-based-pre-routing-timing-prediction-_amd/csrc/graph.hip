@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) seg_mean_fwd_kernel(const float* __restri
 
 __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
     float* __restrict__ G, const float* __restrict__ h, long long ld, const int* __restrict__ rows, int n, int D,
-    const int* __restrict__ on_ptr, const int* __restrict__ on_idx, const int* __restrict__ in_net_ptr,
+    const int* __restrict__ on_ptr, const int* __restrict__ on_idx, const float* __restrict__ on_w,
     const int* __restrict__ oc_ptr, const int* __restrict__ oc_idx, const float* __restrict__ A,
     const float* __restrict__ LSE, const float* __restrict__ DA, int relu) {
   MMFT_NODE_LOOP(n, D) {
@@ -96,14 +96,34 @@ __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
     long long off = (long long)v * ld + c;
     f32x4 hv = ld4(h + off);
     f32x4 g = ld4(G + off);
-    // net consumers: d/dh[v] of mean over the consumer's in-edges
-    for (int e = on_ptr[v]; e < on_ptr[v + 1]; ++e) {
-      int w = on_idx[e];
-      float inv = 1.0f / (float)(in_net_ptr[w + 1] - in_net_ptr[w]);
-      g += ld4(G + (long long)w * ld + c) * inv;
+    // net consumers: d/dh[v] of the mean over the consumer's in-edges (weight = 1/indeg, per out-edge, static).
+    // Four edges are issued together so that the dependent index -> row loads of different edges overlap.
+    int e = on_ptr[v], e1 = on_ptr[v + 1];
+    for (; e + 4 <= e1; e += 4) {
+      int w0 = on_idx[e], w1 = on_idx[e + 1], w2 = on_idx[e + 2], w3 = on_idx[e + 3];
+      float s0 = on_w[e], s1 = on_w[e + 1], s2 = on_w[e + 2], s3 = on_w[e + 3];
+      f32x4 r0 = ld4(G + (long long)w0 * ld + c), r1 = ld4(G + (long long)w1 * ld + c);
+      f32x4 r2 = ld4(G + (long long)w2 * ld + c), r3 = ld4(G + (long long)w3 * ld + c);
+      g += r0 * s0;
+      g += r1 * s1;
+      g += r2 * s2;
+      g += r3 * s3;
     }
+    for (; e < e1; ++e) g += ld4(G + (long long)on_idx[e] * ld + c) * on_w[e];
     // cell consumers: d a_c / d m_jc = w_jc (1 + m_jc - a_c),  w_jc = exp(m_jc - LSE_c)
-    for (int e = oc_ptr[v]; e < oc_ptr[v + 1]; ++e) {
+    e = oc_ptr[v];
+    e1 = oc_ptr[v + 1];
+    for (; e + 2 <= e1; e += 2) {
+      long long o0 = (long long)oc_idx[e] * ld + c, o1 = (long long)oc_idx[e + 1] * ld + c;
+      f32x4 da0 = ld4(DA + o0), a0 = ld4(A + o0), l0 = ld4(LSE + o0);
+      f32x4 da1 = ld4(DA + o1), a1 = ld4(A + o1), l1 = ld4(LSE + o1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        g[j] += da0[j] * expf(hv[j] - l0[j]) * (1.0f + hv[j] - a0[j]);
+        g[j] += da1[j] * expf(hv[j] - l1[j]) * (1.0f + hv[j] - a1[j]);
+      }
+    }
+    for (; e < e1; ++e) {
       long long wo = (long long)oc_idx[e] * ld + c;
       f32x4 da = ld4(DA + wo), a = ld4(A + wo), l = ld4(LSE + wo);
 #pragma unroll
@@ -193,11 +213,11 @@ int mmft_seg_mean_fwd(const float* src, long long lds, const int* in_indptr, con
 }
 
 int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows, int n, int D,
-                        const int* out_net_indptr, const int* out_net_indices, const int* in_net_indptr,
+                        const int* out_net_indptr, const int* out_net_indices, const float* out_net_weight,
                         const int* out_cell_indptr, const int* out_cell_indices, const float* A, const float* LSE,
                         const float* DA, int relu, int device, void* stream) {
   CHECK_ROWS("level_bwd_pull");
-  MMFT_REQUIRE(G && h && out_net_indptr && in_net_indptr && out_cell_indptr && A && LSE && DA,
+  MMFT_REQUIRE(G && h && out_net_indptr && out_cell_indptr && A && LSE && DA,
                "level_bwd_pull: null pointer");
   MMFT_REQUIRE(ld >= D && ld % 4 == 0 && aligned16(G) && aligned16(h) && aligned16(A) && aligned16(LSE) &&
                    aligned16(DA),
@@ -206,7 +226,7 @@ int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows,
   DeviceGuard dg(device);
   ProfScope ps("level_bwd_pull_kernel", 0.0, 3.0 * 4.0 * n * D, (hipStream_t)stream);
   hipLaunchKernelGGL(level_bwd_pull_kernel, dim3(node_grid(n, D)), dim3(256), 0, (hipStream_t)stream, G, h, ld, rows,
-                     n, D, out_net_indptr, out_net_indices, in_net_indptr, out_cell_indptr, out_cell_indices, A, LSE,
+                     n, D, out_net_indptr, out_net_indices, out_net_weight, out_cell_indptr, out_cell_indices, A, LSE,
                      DA, relu);
   return check_launch("level_bwd_pull");
 }

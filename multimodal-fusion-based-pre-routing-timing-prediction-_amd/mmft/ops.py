@@ -210,18 +210,20 @@ def seg_mean_fwd(src, in_csr, rows):
     return out
 
 
-def level_bwd_pull(G, h, rows, out_net, in_net_indptr, out_cell, A, LSE, DA, relu=True):
+def level_bwd_pull(G, h, rows, out_net, out_net_w, out_cell, A, LSE, DA, relu=True):
     for t, nm in ((G, 'G'), (h, 'h'), (A, 'A'), (LSE, 'LSE'), (DA, 'DA')):
         _rows2d(t, nm)
         if t.shape != h.shape or t.stride(0) != h.stride(0):
             raise ValueError(f'level_bwd_pull: {nm} must have the layout of h')
     N = h.shape[0]
     _csr(out_net[0], out_net[1], N, 'out_net'); _csr(out_cell[0], out_cell[1], N, 'out_cell')
-    _idx(in_net_indptr, 'in_net_indptr', N + 1)
+    _chk(out_net_w, 'out_net_w')
+    if out_net_w.numel() != out_net[1].numel() or not out_net_w.is_contiguous():
+        raise ValueError('level_bwd_pull: one weight per out-net edge expected')
     _idx(rows, 'rows')
     n = rows.numel() if rows is not None else N
     dev, st = lib.stream_args(h)
-    lib.call('mmft_level_bwd_pull', G, h, h.stride(0), rows, n, h.shape[1], out_net[0], out_net[1], in_net_indptr,
+    lib.call('mmft_level_bwd_pull', G, h, h.stride(0), rows, n, h.shape[1], out_net[0], out_net[1], out_net_w,
              out_cell[0], out_cell[1], A, LSE, DA, int(relu), dev, st)
     return G
 

@@ -138,6 +138,16 @@ class PinGraph:
                                   torch.from_numpy(idx.astype(np.int32)).to(self.device))
         return self._csr_dev[key]
 
+    def out_net_weight(self):
+        """float32[E_net] aligned with csr('out','net'): 1 / (net in-degree of the edge's destination) - the
+        derivative of fn.mean (src/model.py:186-187) with respect to each source row."""
+        if 'onw' not in self._csr_dev:
+            ip = self._csr_host[('in', 'net')][0]
+            dst = self._csr_host[('out', 'net')][1]
+            indeg = np.diff(ip)[dst]
+            self._csr_dev['onw'] = torch.from_numpy((1.0 / np.maximum(indeg, 1)).astype(np.float32)).to(self.device)
+        return self._csr_dev['onw']
+
     def csr_host(self, direction, etype):
         ip, idx, _ = self._csr_host[(direction, etype)]
         return ip, idx

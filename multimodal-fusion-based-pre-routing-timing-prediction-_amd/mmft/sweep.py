@@ -137,7 +137,7 @@ class LevelFn(torch.autograd.Function):
         P = [_w(p) for p in st.params]
         (w1c, b1c, w2c, b2c, w1n, b1n, w2n, b2n, w1g, b1g, w2g, b2g) = P
         if rows.numel():
-            ops.level_bwd_pull(st.G, st.h, rows, g.csr('out', 'net'), g.csr('in', 'net')[0], g.csr('out', 'cell'),
+            ops.level_bwd_pull(st.G, st.h, rows, g.csr('out', 'net'), g.out_net_weight(), g.csr('out', 'cell'),
                                st.A, st.LSE, st.DA, relu=st.relu)
             if level_id % 2 == 0 and level_id > 0:
                 dhn = ops.linear_dgrad(st.G, w2g, gidx=rows, mask=st.HN, maskidx=rows)
@@ -261,7 +261,7 @@ class SweepFn(torch.autograd.Function):
             ops.scatter_add_rows(st.G, ctx.tix, gout if gout.is_contiguous() else gout.contiguous())
         P = [_w(p) for p in st.params]
         w1g, w2g = P[8], P[10]
-        out_net, out_cell, in_net_ptr = g.csr('out', 'net'), g.csr('out', 'cell'), g.csr('in', 'net')[0]
+        out_net, out_cell, in_net_ptr = g.csr('out', 'net'), g.csr('out', 'cell'), g.out_net_weight()
         for level_id, rows in reversed(st.levels):
             if not rows.numel():
                 continue

@@ -176,5 +176,5 @@ def test_level_bwd_pull_matches_autograd(dev):
     ops.seg_softmax_sum_fwd(h, g.csr('in', 'cell'), cr, A, LSE)
     DA[225:300] = gc.float().to(dev)
     rows = torch.arange(0, 150, dtype=torch.int32, device=dev)
-    ops.level_bwd_pull(G, h, rows, g.csr('out', 'net'), g.csr('in', 'net')[0], g.csr('out', 'cell'), A, LSE, DA, relu=True)
+    ops.level_bwd_pull(G, h, rows, g.csr('out', 'net'), g.out_net_weight(), g.csr('out', 'cell'), A, LSE, DA, relu=True)
     assert rel_err(G[:150], relu_ref) < 5e-5
