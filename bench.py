@@ -92,6 +92,7 @@ def main():
     ap.add_argument('--tile', type=int, default=256)
     ap.add_argument('--batch-paths', type=int, default=1350)
     ap.add_argument('--mode', default='sweep', choices=['sweep', 'dropin'])
+    ap.add_argument('--no-overlap', action='store_true', help='run the sweep and the CNN on one stream')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -119,7 +120,7 @@ def main():
     pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=9294)
     pm_state = {k: v.detach().cpu().clone() for k, v in pmodel.state_dict().items()}
     pc_state = {k: v.detach().cpu().clone() for k, v in cnn.state_dict().items()}
-    ts = TrainStep(pmodel, cnn, designs, dev, world_size=world, mode=args.mode)
+    ts = TrainStep(pmodel, cnn, designs, dev, world_size=world, mode=args.mode, overlap=not args.no_overlap)
     rng = np.random.default_rng(1234 + rank)
     log('resident on device; warm-up')
 

@@ -259,8 +259,32 @@ struct Epi {
     if (m >= M || n >= N) return;
     long long r = rowidx ? (long long)rowidx[m] : (long long)m;
     float* q = C + (long long)z * slab + r * ldc + n;
-    float vv[4] = {v.x, v.y, v.z, v.w};
     int cnt = N - n < 4 ? N - n : 4;
+    if (vec && cnt == 4) {
+      // fast path: whole 16-byte group, vector loads of the old value / the mask
+      if (bias) {
+        v.x += bias[n]; v.y += bias[n + 1]; v.z += bias[n + 2]; v.w += bias[n + 3];
+      }
+      if (mode == EPI_STORE) {
+        v.x = activate(v.x); v.y = activate(v.y); v.z = activate(v.z); v.w = activate(v.w);
+      } else if (mode == EPI_ACCUM) {
+        v += *reinterpret_cast<const f32x4*>(q);
+      } else if (mode == EPI_ADD_ACT) {
+        v += *reinterpret_cast<const f32x4*>(q);
+        v.x = activate(v.x); v.y = activate(v.y); v.z = activate(v.z); v.w = activate(v.w);
+      } else {
+        long long mr = maskidx ? (long long)maskidx[m] : (long long)m;
+        const float* mk = mask + mr * ldmask + n;
+        f32x4 mv;
+        if ((ldmask & 3) == 0 && (reinterpret_cast<uintptr_t>(mask) & 15) == 0) mv = *reinterpret_cast<const f32x4*>(mk);
+        else mv = f32x4{mk[0], mk[1], mk[2], mk[3]};
+        v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
+        v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(q) = v;
+      return;
+    }
+    float vv[4] = {v.x, v.y, v.z, v.w};
     const float* mk = nullptr;
     if (mode == EPI_MASK) {
       long long mr = maskidx ? (long long)maskidx[m] : (long long)m;
@@ -274,16 +298,8 @@ struct Epi {
         else if (mode == EPI_ACCUM) t += q[j];
         else if (mode == EPI_ADD_ACT) t = activate(t + q[j]);
         else t = mk[j] > 0.f ? t : 0.f;
-        vv[j] = t;
+        q[j] = t;
       }
-    }
-    if (vec && cnt == 4) {
-      f32x4 o = {vv[0], vv[1], vv[2], vv[3]};
-      *reinterpret_cast<f32x4*>(q) = o;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j < cnt) q[j] = vv[j];
     }
   }
 };

@@ -97,11 +97,15 @@ _workspace = {}
 
 
 def workspace(device, nbytes):
-    """Per-device scratch buffer (grown on demand, never shrunk) for split-K slabs and reductions."""
-    key = torch.device(device)
+    """Scratch buffer (split-K slabs, BN partials, re-laid-out dgrad weights), grown on demand, never shrunk.
+    One buffer per (device, stream): kernels of the netlist sweep and of the CNN may run concurrently on two
+    streams and must not share scratch."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
     buf = _workspace.get(key)
     need = max(int(nbytes), 1 << 20)
     if buf is None or buf.numel() * 4 < need:
-        buf = torch.empty((need + 3) // 4, dtype=torch.float32, device=key)
+        buf = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
         _workspace[key] = buf
     return buf

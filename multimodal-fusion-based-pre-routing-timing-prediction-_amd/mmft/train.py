@@ -96,11 +96,13 @@ class DesignBatch:
 
 class TrainStep:
     def __init__(self, pmodel, cnn, designs, device, lr=1e-3, weight_decay=0.0, fused_optimizer=True, world_size=1,
-                 mode='sweep'):
+                 mode='sweep', overlap=True):
         """mode='dropin': per-level model() calls exactly as src/train.py:490-511;
         mode='sweep': PathModel.forward_sweep, same arithmetic with level-invariant work hoisted."""
         assert mode in ('dropin', 'sweep')
         self.mode = mode
+        self.overlap = overlap and mode == 'sweep'
+        self.side = torch.cuda.Stream(device=device) if self.overlap else None
         self.pmodel, self.cnn = pmodel, cnn
         self.device = torch.device(device)
         self.batch = DesignBatch(designs, device, pmodel.gnn.out_feat_dim if pmodel.gnn is not None else 128)
@@ -122,13 +124,29 @@ class TrainStep:
     def forward(self, path_ids_per_design):
         b, g = self.batch, self.batch.graph
         ends_d, paths_d, foff_d, counts, ends_h, lv_d = b.select(path_ids_per_design)
-        feat = self.cnn(b.images).reshape(b.B, -1) if self.cnn is not None else None      # src/train.py:465,562
         self.h.zero_()                                                                    # src/train.py:342,559
         g.ndata['h'] = self.h
         if self.mode == 'sweep':
+            # The netlist sweep and the U-Net are independent until the fusion head: the level-serial sweep
+            # (many small, latency-bound launches) runs on a side HIP stream underneath the CNN's large kernels.
+            from . import sweep as _sweep
+            cur = torch.cuda.current_stream(self.device)
+            h_gnn = None
+            if self.pmodel.gnn is not None:
+                if self.overlap:
+                    self.side.wait_stream(cur)
+                    with torch.cuda.stream(self.side):
+                        h_gnn = _sweep.sweep_forward_all(self.pmodel.gnn, g, b.level_nodes, ends_d)
+                else:
+                    h_gnn = _sweep.sweep_forward_all(self.pmodel.gnn, g, b.level_nodes, ends_d)
+            feat = self.cnn(b.images).reshape(b.B, -1) if self.cnn is not None else None
+            if h_gnn is not None and self.overlap:
+                cur.wait_stream(self.side)
+                h_gnn.record_stream(cur)
             pm = MaskedPathMap(b.masks, paths_d, feat, foff_d if b.B > 1 else None, *b.links) \
                 if feat is not None else None
-            return self.pmodel.forward_sweep(g, b.level_nodes, ends_d, lv_d, pm), ends_d, ends_h
+            return self.pmodel.fuse_heads(h_gnn, pm, lv_d, b.L), ends_d, ends_h
+        feat = self.cnn(b.images).reshape(b.B, -1) if self.cnn is not None else None      # src/train.py:465,562
         hats, pos = [], 0
         for level_id in range(b.L):                                                       # src/train.py:490-511
             k = int(counts[level_id])
