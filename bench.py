@@ -93,6 +93,7 @@ def main():
     ap.add_argument('--batch-paths', type=int, default=1350)
     ap.add_argument('--mode', default='sweep', choices=['sweep', 'dropin'])
     ap.add_argument('--no-overlap', action='store_true', help='run the sweep and the CNN on one stream')
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying one HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -123,9 +124,19 @@ def main():
     ts = TrainStep(pmodel, cnn, designs, dev, world_size=world, mode=args.mode, overlap=not args.no_overlap)
     rng = np.random.default_rng(1234 + rank)
     log('resident on device; warm-up')
+    stepper, graphed = ts, False
+    if world == 1 and args.mode == 'sweep' and not args.no_graph:
+        from mmft.train import GraphedTrainStep
+        try:
+            stepper = GraphedTrainStep(ts, sample_paths(designs, args.batch_paths, rng))
+            graphed = True
+            log('train step captured as one HIP graph')
+        except Exception as e:                       # noqa: BLE001 - report and keep the eager path
+            log(f'HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly')
+            stepper = ts
 
     for _w in range(args.warmup):
-        ts.step(sample_paths(designs, args.batch_paths, rng))
+        stepper.step(sample_paths(designs, args.batch_paths, rng))
         torch.cuda.synchronize()
         log(f'warm-up step {_w} done')
     torch.cuda.synchronize()
@@ -135,7 +146,7 @@ def main():
     t0 = time.perf_counter()
     tl = []
     for _it in range(args.steps):
-        loss, hats, tl = ts.step(sample_paths(designs, args.batch_paths, rng))
+        loss, hats, tl = stepper.step(sample_paths(designs, args.batch_paths, rng))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -210,6 +221,7 @@ def main():
                 'designs_per_step_per_gpu': args.designs, 'nodes': args.nodes, 'levels': args.levels,
                 'tile': args.tile, 'endpoints_per_design': args.batch_paths,
                 'parallelism': f'dp{world} (designs sharded, one all-reduce of the flat gradient per step)',
+                'launch': 'one HIP graph replay per step' if graphed else 'eager launches',
                 'api': 'PathModel.forward_sweep (whole-sweep entry; per-level drop-in path: --mode dropin)' if args.mode == 'sweep' else 'drop-in per-level model() calls',
             },
             'nodes_per_s': value * args.nodes,

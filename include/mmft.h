@@ -196,6 +196,12 @@ int mmft_mse_fwd_bwd(const float* pred, const float* target, int n, float* loss,
 int mmft_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, float bias_correction1,
                    float bias_correction2, float gscale, int device, void* stream);
+/* same, with the step-dependent scalars read from DEVICE memory (step_scalars[0] = lr/bias_correction1,
+ * step_scalars[1] = sqrt(bias_correction2)) so that the launch can be captured once in a HIP graph and
+ * replayed every step */
+int mmft_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* step_scalars,
+                       float beta1, float beta2, float eps, float weight_decay, float gscale,
+                       int device, void* stream);
 
 #ifdef __cplusplus
 }

@@ -113,7 +113,12 @@ __global__ void __launch_bounds__(1024) mse_kernel(const float* __restrict__ pre
 
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float step_size, float beta1,
-                                                   float beta2, float eps, float wd, float bc2_sqrt, float gscale) {
+                                                   float beta2, float eps, float wd, float bc2_sqrt, float gscale,
+                                                   const float* __restrict__ dev_scalars) {
+  if (dev_scalars) {
+    step_size = dev_scalars[0];
+    bc2_sqrt = dev_scalars[1];
+  }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     float gi = g[i] * gscale, pi = p[i];
     if (wd != 0.f) gi += wd * pi;
@@ -184,8 +189,19 @@ int mmft_adam_step(float* p, const float* g, float* m, float* v, long long n, fl
   DeviceGuard dg(device);
   ProfScope ps("adam_kernel", 0.0, 28.0 * n, (hipStream_t)stream);
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr / bias_correction1,
-                     beta1, beta2, eps, weight_decay, sqrtf(bias_correction2), gscale);
+                     beta1, beta2, eps, weight_decay, sqrtf(bias_correction2), gscale, (const float*)nullptr);
   return check_launch("adam_step");
+}
+
+int mmft_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* step_scalars, float beta1,
+                       float beta2, float eps, float weight_decay, float gscale, int device, void* stream) {
+  MMFT_REQUIRE(p && g && m && v && step_scalars && n >= 0, "adam_step_dev: bad args");
+  if (n == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  ProfScope ps("adam_kernel", 0.0, 28.0 * n, (hipStream_t)stream);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, 0.f, beta1, beta2, eps,
+                     weight_decay, 1.f, gscale, step_scalars);
+  return check_launch("adam_step_dev");
 }
 
 }  // extern "C"

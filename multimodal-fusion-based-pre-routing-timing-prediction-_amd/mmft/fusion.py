@@ -234,6 +234,29 @@ class FlatAdam:
         lib.call('mmft_adam_step', self.flat_param, self.flat_grad, self.m, self.v, self.n, float(self.lr), float(b1),
                  float(b2), float(self.eps), float(self.wd), float(bc1), float(bc2), float(gscale), dev, st)
 
+    # ---- graph-capturable form: the step-dependent scalars live in device memory
+    def prepare_step(self):
+        """Advance the step counter and upload lr/bc1, sqrt(bc2) (call OUTSIDE graph capture/replay)."""
+        import math
+        self.ensure_scalars()
+        self.step_count += 1
+        b1, b2 = self.betas
+        self._scal_host[0] = self.lr / (1.0 - b1 ** self.step_count)
+        self._scal_host[1] = math.sqrt(1.0 - b2 ** self.step_count)
+        self._scal_dev.copy_(self._scal_host, non_blocking=True)
+
+    def ensure_scalars(self):
+        if not hasattr(self, '_scal_host'):
+            self._scal_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+            self._scal_dev = torch.zeros(2, dtype=torch.float32, device=self.flat_param.device)
+
+    def step_captured(self, gscale=1.0):
+        """The Adam launch with scalars read from device memory (safe inside HIP-graph capture)."""
+        b1, b2 = self.betas
+        dev, st = lib.stream_args(self.flat_param)
+        lib.call('mmft_adam_step_dev', self.flat_param, self.flat_grad, self.m, self.v, self.n, self._scal_dev, float(b1),
+                 float(b2), float(self.eps), float(self.wd), float(gscale), dev, st)
+
 
 def _dense(t):
     """non-overlapping and dense (any permutation of a contiguous block)."""

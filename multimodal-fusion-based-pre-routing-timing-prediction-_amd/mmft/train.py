@@ -76,7 +76,7 @@ class DesignBatch:
         self.path2endpoint = np.concatenate([d.path2endpoint + self.node_off[i] for i, d in enumerate(designs)])
         self.path2design = np.concatenate([np.full(d.num_paths, i, dtype=np.int64) for i, d in enumerate(designs)])
 
-    def select(self, path_ids_per_design):
+    def select(self, path_ids_per_design, static=None):
         """Bucket the sampled paths by level (src/train.py:476-484); order inside a level = design, then
         order of appearance.  One host->device copy for the whole step."""
         gp = np.concatenate([np.asarray(p, dtype=np.int64) + self.path_off[i]
@@ -89,7 +89,13 @@ class DesignBatch:
         first, nxt = batch_links(gp, self.path2level.shape[0])
         T = gp.shape[0]
         packed = np.concatenate([ends, gp, self.path2design[gp] * self.P, lv, nxt, first]).astype(np.int32)
-        dev = torch.from_numpy(packed).to(self.device)
+        if static is not None:
+            if static.numel() != packed.shape[0]:
+                raise ValueError('graph replay needs a constant number of sampled paths per step')
+            static.copy_(torch.from_numpy(packed), non_blocking=True)
+            dev = static
+        else:
+            dev = torch.from_numpy(packed).to(self.device)
         self.links = (dev[5 * T:], dev[4 * T:5 * T])
         return dev[0:T], dev[T:2 * T], dev[2 * T:3 * T], counts, ends, dev[3 * T:4 * T]
 
@@ -121,9 +127,9 @@ class TrainStep:
         self.h = torch.zeros((self.batch.N, self.batch.out_dim), dtype=torch.float32, device=self.device)
 
     # ---------------------------------------------------------------- forward of one mini-batch
-    def forward(self, path_ids_per_design):
+    def forward(self, path_ids_per_design, _sel=None):
         b, g = self.batch, self.batch.graph
-        ends_d, paths_d, foff_d, counts, ends_h, lv_d = b.select(path_ids_per_design)
+        ends_d, paths_d, foff_d, counts, ends_h, lv_d = _sel if _sel is not None else b.select(path_ids_per_design)
         self.h.zero_()                                                                    # src/train.py:342,559
         g.ndata['h'] = self.h
         if self.mode == 'sweep':
@@ -174,3 +180,60 @@ class TrainStep:
         else:
             self.optim.step()
         return loss.detach(), hats.detach(), ends_h.tolist()
+
+
+class GraphedTrainStep:
+    """The whole mini-batch (forward, MSE, backward, fused Adam) captured ONCE as a HIP graph and replayed per
+    step: the ~550 kernel launches of a step then cost no host time.  Per step the host only packs the sampled
+    endpoints into one pinned int32 buffer (one H2D copy into a static device buffer) and uploads Adam's two
+    bias-correction scalars.  Requires a constant number of sampled paths per step and world_size == 1
+    (the multi-GPU path runs eagerly so that the RCCL all-reduce stays outside any capture)."""
+
+    def __init__(self, ts, example_path_ids, warmup=3):
+        if ts.world_size != 1 or not ts.fused or ts.mode != 'sweep':
+            raise ValueError('GraphedTrainStep needs mode="sweep", the fused optimizer and a single rank')
+        self.ts = ts
+        b = ts.batch
+        for _ in range(warmup):                       # optional eager optimizer steps before the capture
+            ts.step(example_path_ids)
+        # one eager forward + backward WITHOUT an optimizer step: uploads the cached level rows and allocates
+        # every workspace / sweep buffer, none of which may happen while the stream is capturing.  Run on a
+        # side stream (as torch's capture recipe asks) and drop every reference to its autograd graph before
+        # capturing, otherwise stale AccumulateGrad nodes bound to another stream break the capture.
+        warm = torch.cuda.Stream(device=ts.device)
+        warm.wait_stream(torch.cuda.current_stream(ts.device))
+        with torch.cuda.stream(warm):
+            hats0, ends0, _ = ts.forward(example_path_ids)
+            ts.optim.zero_grad()
+            loss0 = mse_loss(hats0, b.arrival[ends0.long()].squeeze(-1))
+            loss0.backward()
+            ts.optim.zero_grad()
+            del hats0, ends0, loss0
+        torch.cuda.current_stream(ts.device).wait_stream(warm)
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        sel = b.select(example_path_ids)
+        T = sel[0].numel()
+        self.static_idx = torch.zeros(5 * T + b.path2level.shape[0], dtype=torch.int32, device=ts.device)
+        self.T = T
+        sel = b.select(example_path_ids, static=self.static_idx)
+        ts.optim.ensure_scalars()          # buffers only: capturing records the launch, it does not take a step
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            hats, ends_d, _ = ts.forward(None, _sel=sel)
+            arrival = b.arrival[ends_d.long()].squeeze(-1)
+            loss = mse_loss(hats, arrival)
+            ts.optim.zero_grad()
+            loss.backward()
+            ts.optim.step_captured()
+            self.loss, self.hats = loss.detach(), hats.detach()
+        torch.cuda.synchronize()
+
+    def step(self, path_ids_per_design):
+        b = self.ts.batch
+        sel = b.select(path_ids_per_design, static=self.static_idx)
+        self.ts.optim.prepare_step()
+        self.graph.replay()
+        return self.loss, self.hats, sel[4].tolist()
