@@ -40,37 +40,58 @@ static int conv_fwd_launch(const float* x, const float* w, const float* bias, fl
 // the group (removes the mean offset from the E[x^2]-E[x]^2 cancellation); stage 2 combines in fp64.
 constexpr int BN_ROWS_PER_BLOCK = 512;
 
+// C % 4 == 0: a thread owns one 4-channel group (16-byte loads) and walks the rows of its block with two rows in
+// flight; C % 4 != 0 falls back to one channel per thread.
+template <int VEC>
 __global__ void __launch_bounds__(256) bn_partial_kernel(const float* __restrict__ x, long long rows, int C,
                                                          int blocks_per_group, float* __restrict__ partial) {
-  __shared__ float red[2][256];
+  __shared__ float red[2][256 * VEC];
   int grp = blockIdx.x / blocks_per_group, blk = blockIdx.x % blocks_per_group;
   const float* xg = x + (long long)grp * rows * C;
   long long r0 = (long long)blk * BN_ROWS_PER_BLOCK;
   long long r1 = r0 + BN_ROWS_PER_BLOCK < rows ? r0 + BN_ROWS_PER_BLOCK : rows;
-  int lanes_per_row = C < 256 ? C : 256;           // C <= 256 assumed by host check
+  const int cg = C / VEC;                              // channel groups per row
+  int lanes_per_row = cg < 256 ? cg : 256;
   int rstep = 256 / lanes_per_row;
-  int c = threadIdx.x % lanes_per_row, rl = threadIdx.x / lanes_per_row;
-  float s = 0.f, ss = 0.f;
+  int c = (threadIdx.x % lanes_per_row) * VEC, rl = threadIdx.x / lanes_per_row;
+  float s[VEC], ss[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s[j] = ss[j] = 0.f;
   if (rl < rstep) {
-    float shift = xg[c];
+    float shift[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) shift[j] = xg[c + j];
     for (long long r = r0 + rl; r < r1; r += rstep) {
-      float v = xg[r * C + c] - shift;
-      s += v;
-      ss += v * v;
+      if (VEC == 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(xg + r * C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float d = v[j] - shift[j];
+          s[j] += d;
+          ss[j] += d * d;
+        }
+      } else {
+        float d = xg[r * C + c] - shift[0];
+        s[0] += d;
+        ss[0] += d * d;
+      }
     }
   }
-  red[0][threadIdx.x] = s;
-  red[1][threadIdx.x] = ss;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    red[0][threadIdx.x * VEC + j] = s[j];
+    red[1][threadIdx.x * VEC + j] = ss[j];
+  }
   __syncthreads();
-  if (threadIdx.x < lanes_per_row) {
-    float a = 0.f, b = 0.f;
+  for (int cc = threadIdx.x; cc < C && cc < lanes_per_row * VEC; cc += 256) {
+    float a = 0.f, bsum = 0.f;
     for (int j = 0; j < rstep; ++j) {
-      a += red[0][j * lanes_per_row + threadIdx.x];
-      b += red[1][j * lanes_per_row + threadIdx.x];
+      a += red[0][j * lanes_per_row * VEC + cc];
+      bsum += red[1][j * lanes_per_row * VEC + cc];
     }
     float* q = partial + ((long long)blockIdx.x * 2) * C;
-    q[threadIdx.x] = a;
-    q[C + threadIdx.x] = b;
+    q[cc] = a;
+    q[C + cc] = bsum;
   }
 }
 
@@ -122,57 +143,96 @@ __global__ void __launch_bounds__(256) bn_running_kernel(const float* __restrict
   running_var[c] = (float)rv;
 }
 
+template <int VEC>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        long long rows, int C, long long total, int relu) {
   long long per_group = rows * C;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VEC; i < total;
+       i += (long long)gridDim.x * blockDim.x * VEC) {
     int c = (int)(i % C);
     int g = (int)(i / per_group);
-    float v = (x[i] - mean[g * C + c]) * invstd[g * C + c] * gamma[c] + beta[c];
-    if (relu) v = v > 0.f ? v : 0.f;
-    y[i] = v;
+    if (VEC == 4) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = (v[j] - mean[g * C + c + j]) * invstd[g * C + c + j] * gamma[c + j] + beta[c + j];
+        v[j] = (relu && !(t > 0.f)) ? 0.f : t;
+      }
+      *reinterpret_cast<f32x4*>(y + i) = v;
+    } else {
+      float t = (x[i] - mean[g * C + c]) * invstd[g * C + c] * gamma[c] + beta[c];
+      y[i] = (relu && !(t > 0.f)) ? 0.f : t;
+    }
   }
 }
 
 // backward stage 1: partial sums of g and g*xhat (g = gy masked by the ReLU output)
+template <int VEC>
 __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                              const float* __restrict__ y, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, long long rows, int C,
                                                              int blocks_per_group, int relu,
                                                              float* __restrict__ partial) {
-  __shared__ float red[2][256];
+  __shared__ float red[2][256 * VEC];
   int grp = blockIdx.x / blocks_per_group, blk = blockIdx.x % blocks_per_group;
   long long base = (long long)grp * rows * C;
   long long r0 = (long long)blk * BN_ROWS_PER_BLOCK;
   long long r1 = r0 + BN_ROWS_PER_BLOCK < rows ? r0 + BN_ROWS_PER_BLOCK : rows;
-  int lanes_per_row = C < 256 ? C : 256;
+  const int cg = C / VEC;
+  int lanes_per_row = cg < 256 ? cg : 256;
   int rstep = 256 / lanes_per_row;
-  int c = threadIdx.x % lanes_per_row, rl = threadIdx.x / lanes_per_row;
-  float s = 0.f, sx = 0.f;
+  int c = (threadIdx.x % lanes_per_row) * VEC, rl = threadIdx.x / lanes_per_row;
+  float s[VEC], sx[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s[j] = sx[j] = 0.f;
   if (rl < rstep) {
-    float mu = mean[grp * C + c], is = invstd[grp * C + c];
+    float mu[VEC], is[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      mu[j] = mean[grp * C + c + j];
+      is[j] = invstd[grp * C + c + j];
+    }
     for (long long r = r0 + rl; r < r1; r += rstep) {
       long long i = base + r * C + c;
-      float g = gy[i];
-      if (relu && !(y[i] > 0.f)) g = 0.f;
-      s += g;
-      sx += g * (x[i] - mu) * is;
+      if (VEC == 4) {
+        f32x4 g = *reinterpret_cast<const f32x4*>(gy + i);
+        f32x4 xv = *reinterpret_cast<const f32x4*>(x + i);
+        if (relu) {
+          f32x4 yv = *reinterpret_cast<const f32x4*>(y + i);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (!(yv[j] > 0.f)) g[j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s[j] += g[j];
+          sx[j] += g[j] * (xv[j] - mu[j]) * is[j];
+        }
+      } else {
+        float g = gy[i];
+        if (relu && !(y[i] > 0.f)) g = 0.f;
+        s[0] += g;
+        sx[0] += g * (x[i] - mu[0]) * is[0];
+      }
     }
   }
-  red[0][threadIdx.x] = s;
-  red[1][threadIdx.x] = sx;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    red[0][threadIdx.x * VEC + j] = s[j];
+    red[1][threadIdx.x * VEC + j] = sx[j];
+  }
   __syncthreads();
-  if (threadIdx.x < lanes_per_row) {
-    float a = 0.f, b = 0.f;
+  for (int cc = threadIdx.x; cc < C && cc < lanes_per_row * VEC; cc += 256) {
+    float a = 0.f, bsum = 0.f;
     for (int j = 0; j < rstep; ++j) {
-      a += red[0][j * lanes_per_row + threadIdx.x];
-      b += red[1][j * lanes_per_row + threadIdx.x];
+      a += red[0][j * lanes_per_row * VEC + cc];
+      bsum += red[1][j * lanes_per_row * VEC + cc];
     }
     float* q = partial + ((long long)blockIdx.x * 2) * C;
-    q[threadIdx.x] = a;
-    q[C + threadIdx.x] = b;
+    q[cc] = a;
+    q[C + cc] = bsum;
   }
 }
 
@@ -207,20 +267,41 @@ __global__ void __launch_bounds__(256) bn_bwd_params_kernel(const float* __restr
   dbeta[c] = (float)(db * (double)rows);
 }
 
+template <int VEC>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                            const float* __restrict__ y, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, float* __restrict__ dx,
                                                            long long rows, int C, long long total, int relu) {
   long long per_group = rows * C;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VEC; i < total;
+       i += (long long)gridDim.x * blockDim.x * VEC) {
     int c = (int)(i % C);
     int g = (int)(i / per_group);
-    float gg = gy[i];
-    if (relu && !(y[i] > 0.f)) gg = 0.f;
-    float is = invstd[g * C + c];
-    float xh = (x[i] - mean[g * C + c]) * is;
-    dx[i] = gamma[c] * is * (gg - coef[(g * 2) * C + c] - xh * coef[(g * 2 + 1) * C + c]);
+    if (VEC == 4) {
+      f32x4 gg = *reinterpret_cast<const f32x4*>(gy + i);
+      f32x4 xv = *reinterpret_cast<const f32x4*>(x + i);
+      if (relu) {
+        f32x4 yv = *reinterpret_cast<const f32x4*>(y + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (!(yv[j] > 0.f)) gg[j] = 0.f;
+      }
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float is = invstd[g * C + c + j];
+        float xh = (xv[j] - mean[g * C + c + j]) * is;
+        o[j] = gamma[c + j] * is * (gg[j] - coef[(g * 2) * C + c + j] - xh * coef[(g * 2 + 1) * C + c + j]);
+      }
+      *reinterpret_cast<f32x4*>(dx + i) = o;
+    } else {
+      float gg = gy[i];
+      if (relu && !(y[i] > 0.f)) gg = 0.f;
+      float is = invstd[g * C + c];
+      float xh = (x[i] - mean[g * C + c]) * is;
+      dx[i] = gamma[c] * is * (gg - coef[(g * 2) * C + c] - xh * coef[(g * 2 + 1) * C + c]);
+    }
   }
 }
 
@@ -436,7 +517,9 @@ int mmft_bn_train_fwd(const float* x, float* y, const float* gamma, const float*
   hipStream_t st = (hipStream_t)stream;
   int bpg = bn_blocks(rows);
   ProfScope ps("bn_train_fwd(4 kernels)", 0.0, 3.0 * 4.0 * groups * rows * C, st);
-  hipLaunchKernelGGL(bn_partial_kernel, dim3(groups * bpg), dim3(256), 0, st, x, rows, C, bpg, workspace);
+  const bool v4 = (C % 4 == 0) && aligned16(x) && aligned16(y);
+  if (v4) hipLaunchKernelGGL(bn_partial_kernel<4>, dim3(groups * bpg), dim3(256), 0, st, x, rows, C, bpg, workspace);
+  else hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(groups * bpg), dim3(256), 0, st, x, rows, C, bpg, workspace);
   float* save_var = workspace + (long long)groups * bpg * 2 * C;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(groups * C), dim3(64), 0, st, x, workspace, rows, C, bpg, eps, save_mean,
                      save_invstd, save_var);
@@ -444,8 +527,12 @@ int mmft_bn_train_fwd(const float* x, float* y, const float* gamma, const float*
     hipLaunchKernelGGL(bn_running_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, save_mean, save_var, groups, rows, C,
                        momentum, running_mean, running_var);
   long long total = (long long)groups * rows * C;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y, gamma, beta, save_mean, save_invstd,
-                     rows, C, total, relu);
+  if (v4)
+    hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(ew_grid(total / 4)), dim3(256), 0, st, x, y, gamma, beta, save_mean,
+                       save_invstd, rows, C, total, relu);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(ew_grid(total)), dim3(256), 0, st, x, y, gamma, beta, save_mean,
+                       save_invstd, rows, C, total, relu);
   return check_launch("bn_train_fwd");
 }
 
@@ -461,13 +548,22 @@ int mmft_bn_train_bwd(const float* gy, const float* x, const float* y, const flo
   int bpg = bn_blocks(rows);
   float* coef = workspace + (long long)groups * bpg * 2 * C;
   ProfScope ps("bn_train_bwd(4 kernels)", 0.0, 7.0 * 4.0 * groups * rows * C, st);
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(groups * bpg), dim3(256), 0, st, gy, x, y, save_mean, save_invstd, rows, C,
-                     bpg, relu, workspace);
+  const bool v4 = (C % 4 == 0) && aligned16(x) && aligned16(gy) && aligned16(dx) && (!y || aligned16(y));
+  if (v4)
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<4>, dim3(groups * bpg), dim3(256), 0, st, gy, x, y, save_mean, save_invstd, rows,
+                       C, bpg, relu, workspace);
+  else
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<1>, dim3(groups * bpg), dim3(256), 0, st, gy, x, y, save_mean, save_invstd, rows,
+                       C, bpg, relu, workspace);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(groups * C), dim3(64), 0, st, workspace, rows, C, bpg, coef);
   hipLaunchKernelGGL(bn_bwd_params_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, coef, groups, rows, C, dgamma, dbeta);
   long long total = (long long)groups * rows * C;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, gy, x, y, gamma, save_mean, save_invstd,
-                     coef, dx, rows, C, total, relu);
+  if (v4)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_grid(total / 4)), dim3(256), 0, st, gy, x, y, gamma, save_mean,
+                       save_invstd, coef, dx, rows, C, total, relu);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_grid(total)), dim3(256), 0, st, gy, x, y, gamma, save_mean,
+                       save_invstd, coef, dx, rows, C, total, relu);
   return check_launch("bn_train_bwd");
 }
 

@@ -507,6 +507,13 @@ inline int launch_gemm(const XL& xl, const WL& wl, const Epi& epi, int M, int N,
       }
   }
   if (pick < 0) pick = ncand - 1;
+  // Short level-serial GEMMs (few rows, K <= 512): a 16-deep K step costs one global round trip (~1 us) for 4-16
+  // MFMAs, so the tile's K loop is latency-bound.  BK = 64 makes a quarter of the round trips with four times the
+  // bytes in flight per thread.
+  if (splits <= 1 && K >= 64 && K <= 512 && (long long)M * N <= (1ll << 23) && ncap >= 64 && mcap >= 32) {
+    launch_cfg<TileCfg<32, 64, 64, 2, 2>>(xl, wl, epi, M, N, K, splits, st);
+    return check_launch("gemm_f32");
+  }
 #define MMFT_GO(BM, BN, WM, WN) launch_cfg<TileCfg<BM, BN, 16, WM, WN>>(xl, wl, epi, M, N, K, splits, st)
   switch (cand[pick][0] * 1000 + cand[pick][1]) {
     case 128128: MMFT_GO(128, 128, 2, 2); break;
