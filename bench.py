@@ -45,6 +45,29 @@ def sample_paths(designs, batch_paths, rng):
     return [rng.permutation(d.num_paths)[:min(batch_paths, d.num_paths)] for d in designs]
 
 
+def _norm_kernel(name):
+    name = name.split('(')[0] if not name.startswith('bn_train') else name
+    for t in ('void ', 'mmft::', ' '):
+        name = name.replace(t, '')
+    return name
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_hbm_traffic.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this bench, KiB units, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when the kernel has no entry."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    want = _norm_kernel(kernel)
+    for k, v in table.items():
+        if _norm_kernel(k) == want:
+            return v['hbm_bytes_per_launch']
+    return None
+
+
 def prof_report():
     from mmft import lib
     L = lib.load()
@@ -187,6 +210,7 @@ def main():
             ach = top['bytes'] / (top['ms'] * 1e-3) / 1e9
             roofline = dict(bound='hbm', achieved=ach, peak=PEAK_HBM_GBS, unit='GB/s', frac=ach / PEAK_HBM_GBS,
                             traffic=None)
+        roofline['traffic'] = pmc_traffic(top['name'])
         roofline.update(kernel=top['name'], launches_per_step=top['launches'] / nprof,
                         avg_launch_us=per_launch_ms * 1e3, share_of_device_time=top['ms'] / total_ms,
                         device_ms_per_step=total_ms / nprof,
