@@ -88,6 +88,11 @@ int mmft_seg_softmax_sum_fwd(const float* h, long long ldh, const int* in_indptr
 /* h[v] = act(h[v] + mean_{u->v} h[u])   (h[v] holds fc_net_self(x_net[v]) on entry; 0 for degree 0) */
 int mmft_seg_mean_add_act_fwd(float* h, long long ldh, const int* in_indptr, const int* in_indices,
                               const int* rows, int n, int D, int relu, int device, void* stream);
+/* out[i] (+)= sum over the CSR segment of rows[i] of src[u]  (deterministic segmented row sum; with
+ * accumulate != 0 the result is added to out[rows[i]] in place) */
+int mmft_seg_sum_fwd(const float* src, long long lds, const int* indptr, const int* indices,
+                     const int* rows, int n, int D, float* out, long long ldo, int accumulate,
+                     int device, void* stream);
 /* out[v] = mean_{u->v} src[u]  (standalone fn.mean) */
 int mmft_seg_mean_fwd(const float* src, long long lds, const int* in_indptr, const int* in_indices,
                       const int* rows, int n, int D, float* out, long long ldo, int device, void* stream);

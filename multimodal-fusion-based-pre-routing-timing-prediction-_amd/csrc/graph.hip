@@ -67,14 +67,14 @@ __global__ void __launch_bounds__(256) seg_mean_fwd_kernel(const float* __restri
                                                            const int* __restrict__ indices,
                                                            const int* __restrict__ rows, int n, int D,
                                                            float* __restrict__ out, long long ldo, int add_self,
-                                                           int relu) {
+                                                           int relu, int do_mean) {
   MMFT_NODE_LOOP(n, D) {
     int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
     int v = rows ? rows[i] : i;
     int e0 = indptr[v], e1 = indptr[v + 1];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int e = e0; e < e1; ++e) acc += ld4(src + (long long)indices[e] * lds + c);
-    if (e1 > e0) acc = acc * (1.0f / (float)(e1 - e0));
+    if (do_mean && e1 > e0) acc = acc * (1.0f / (float)(e1 - e0));
     float* o = add_self ? out + (long long)v * ldo + c : out + (long long)i * ldo + c;
     if (add_self) acc += ld4(o);
     if (relu) {
@@ -194,7 +194,7 @@ int mmft_seg_mean_add_act_fwd(float* h, long long ldh, const int* in_indptr, con
   DeviceGuard dg(device);
   ProfScope ps("seg_mean_fwd_kernel", 0.0, 3.0 * 4.0 * n * D, (hipStream_t)stream);
   hipLaunchKernelGGL(seg_mean_fwd_kernel, dim3(node_grid(n, D)), dim3(256), 0, (hipStream_t)stream, h, ldh, in_indptr,
-                     in_indices, rows, n, D, h, ldh, 1, relu);
+                     in_indices, rows, n, D, h, ldh, 1, relu, 1);
   return check_launch("seg_mean_add_act_fwd");
 }
 
@@ -208,8 +208,22 @@ int mmft_seg_mean_fwd(const float* src, long long lds, const int* in_indptr, con
   DeviceGuard dg(device);
   ProfScope ps("seg_mean_fwd_kernel", 0.0, 3.0 * 4.0 * n * D, (hipStream_t)stream);
   hipLaunchKernelGGL(seg_mean_fwd_kernel, dim3(node_grid(n, D)), dim3(256), 0, (hipStream_t)stream, src, lds,
-                     in_indptr, in_indices, rows, n, D, out, ldo, 0, 0);
+                     in_indptr, in_indices, rows, n, D, out, ldo, 0, 0, 1);
   return check_launch("seg_mean_fwd");
+}
+
+int mmft_seg_sum_fwd(const float* src, long long lds, const int* indptr, const int* indices, const int* rows, int n,
+                     int D, float* out, long long ldo, int accumulate, int device, void* stream) {
+  CHECK_ROWS("seg_sum_fwd");
+  MMFT_REQUIRE(src && indptr && out, "seg_sum_fwd: null pointer");
+  MMFT_REQUIRE(lds >= D && ldo >= D && lds % 4 == 0 && ldo % 4 == 0 && aligned16(src) && aligned16(out),
+               "seg_sum_fwd: rows must be 16-byte aligned");
+  if (n == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  ProfScope ps("seg_mean_fwd_kernel", 0.0, 3.0 * 4.0 * n * D, (hipStream_t)stream);
+  hipLaunchKernelGGL(seg_mean_fwd_kernel, dim3(node_grid(n, D)), dim3(256), 0, (hipStream_t)stream, src, lds, indptr,
+                     indices, rows, n, D, out, ldo, accumulate ? 1 : 0, 0, 0);
+  return check_launch("seg_sum_fwd");
 }
 
 int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows, int n, int D,

@@ -48,7 +48,8 @@ def linear_act(x, w, b=None, slope=None):
 
 
 class GatherRowsFn(torch.autograd.Function):
-    """out[i] = table[idx[i]] (idx int32 on the device); backward = atomic scatter-add (duplicates allowed)."""
+    """out[i] = table[idx[i]] (idx int32 on the device); backward = segmented row sums in a fixed order for small
+    tables (bitwise reproducible), float atomics otherwise."""
 
     @staticmethod
     def forward(ctx, table, idx):
@@ -61,7 +62,11 @@ class GatherRowsFn(torch.autograd.Function):
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
         out = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
-        ops.scatter_add_rows(out, idx, g if g.is_contiguous() else g.contiguous())
+        gg = g if g.is_contiguous() else g.contiguous()
+        if ctx.shape[0] <= 4096:
+            ops.scatter_add_rows_det(out, idx, gg)       # small table, many duplicates: fixed summation order
+        else:
+            ops.scatter_add_rows(out, idx, gg)
         return out, None
 
 

@@ -210,6 +210,19 @@ def seg_mean_fwd(src, in_csr, rows):
     return out
 
 
+def scatter_add_rows_det(dst, idx, src):
+    """dst[idx[i]] += src[i], bitwise reproducible: rows are grouped by a stable sort of idx and every destination
+    row sums its contributions in batch order (no float atomics).  Meant for small destination tables."""
+    _rows2d(dst, 'dst'); _rows2d(src, 'src'); _idx(idx, 'idx', src.shape[0])
+    R = dst.shape[0]
+    sidx, perm = torch.sort(idx.long(), stable=True)
+    indptr = torch.searchsorted(sidx, torch.arange(R + 1, device=idx.device)).to(torch.int32)
+    dev, st = lib.stream_args(dst)
+    lib.call('mmft_seg_sum_fwd', src, src.stride(0), indptr, perm.to(torch.int32), None, R, dst.shape[1], dst,
+             dst.stride(0), 1, dev, st)
+    return dst
+
+
 def level_bwd_pull(G, h, rows, out_net, out_net_w, out_cell, A, LSE, DA, relu=True):
     for t, nm in ((G, 'G'), (h, 'h'), (A, 'A'), (LSE, 'LSE'), (DA, 'DA')):
         _rows2d(t, nm)
