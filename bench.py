@@ -124,6 +124,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('MMFT_DIST_BACKEND', 'nccl') != 'nccl':
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)      # rehearsal: ranks may share a GPU
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the hot path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
@@ -131,7 +133,12 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)          # backend "nccl" is RCCL on ROCm
+        # backend "nccl" is RCCL on ROCm; MMFT_DIST_BACKEND=gloo only for rehearsing the N>1 path on one GPU
+        backend = os.environ.get('MMFT_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from mmft.synth import synth_design
     from mmft.train import build_models, TrainStep
@@ -148,7 +155,7 @@ def main():
     rng = np.random.default_rng(1234 + rank)
     log('resident on device; warm-up')
     stepper, graphed = ts, False
-    if world == 1 and args.mode == 'sweep' and not args.no_graph:
+    if args.mode == 'sweep' and not args.no_graph:
         from mmft.train import GraphedTrainStep
         try:
             stepper = GraphedTrainStep(ts, sample_paths(designs, args.batch_paths, rng))
@@ -177,21 +184,25 @@ def main():
     elapsed = time.perf_counter() - t0
     log(f'timed region: {elapsed / args.steps * 1e3:.2f} ms/step')
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     mae = float((hats - ts.batch.arrival[torch.as_tensor(tl, device=dev).long()].squeeze(-1)).abs().mean())
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
+        # every rank runs the instrumented steps (the all-reduce needs all of them); only rank 0 records events
         L = lib.load()
-        L.mmft_prof_reset()
-        L.mmft_prof_enable(1)
+        if rank == 0:
+            L.mmft_prof_reset()
+            L.mmft_prof_enable(1)
         nprof = min(args.steps, 3)
         for _i in range(nprof):
             ts.step(sample_paths(designs, args.batch_paths, rng))
         torch.cuda.synchronize()
-        L.mmft_prof_enable(0)
+        if rank == 0:
+            L.mmft_prof_enable(0)
+    if rank == 0 and not args.no_roofline:
         log('profiled steps done')
         rows = sorted(prof_report(), key=lambda r: -r['ms'])
         L.mmft_prof_reset()
@@ -240,12 +251,13 @@ def main():
             'dtype': 'f32',
             'data': 'synthetic',
             'config': {
-                'workload': f'config B: {args.designs} designs/step/GPU, {args.nodes}-node netlist, {args.levels} levels, '
+                'workload': f'{"config B" if (args.designs, args.nodes, args.levels, args.tile) == (8, 65536, 64, 256) else "custom"}: {args.designs} designs/step/GPU, {args.nodes}-node netlist, {args.levels} levels, '
                             f'{args.tile}x{args.tile} tile, {args.batch_paths} endpoints/design, UNet(max), fp32',
                 'designs_per_step_per_gpu': args.designs, 'nodes': args.nodes, 'levels': args.levels,
                 'tile': args.tile, 'endpoints_per_design': args.batch_paths,
                 'parallelism': f'dp{world} (designs sharded, one all-reduce of the flat gradient per step)',
-                'launch': 'one HIP graph replay per step' if graphed else 'eager launches',
+                'launch': ('one HIP graph replay per step' + ('' if world == 1 else ' (forward+backward) + eager all-reduce + Adam'))
+                if graphed else 'eager launches',
                 'api': 'PathModel.forward_sweep (whole-sweep entry; per-level drop-in path: --mode dropin)' if args.mode == 'sweep' else 'drop-in per-level model() calls',
             },
             'nodes_per_s': value * args.nodes,

@@ -64,6 +64,18 @@ long long mmft_linear_wgrad_workspace_bytes(int rows, int out, int in);
 int mmft_linear_wgrad(const float* g, const int* gidx, long long ldg, const float* x, const int* xidx,
                       long long ldx, float* dw, long long lddw, int rows, int out, int in, int accumulate,
                       float* workspace, long long workspace_bytes, int device, void* stream);
+/* Fused Linear-ReLU-Linear over gathered rows, hidden tile kept in LDS (one launch per cell level of the sweep;
+ * PathConv.apply_cell_func's fc_cell_neigh, src/model.py:138-146, and its backward):
+ *   hid = mask ? (x1[rows] . W1) * (mask[rows] > 0) : relu(x1[rows] . W1 + b1)
+ *   out[rows] = add_act ? act(out[rows] + hid . W2 + b2) : hid . W2 + b2          (act = ReLU if relu_out)
+ * weights_kmajor = 0: W1 is [HD][K1], W2 is [D2][HD] (torch Linear layout, forward);
+ * weights_kmajor = 1: W1 is [K1][HD], W2 is [HD][D2] (the same parameters read transposed, backward).
+ * hid_out (optional) receives the hidden rows.  Only K1=128, HD=256, D2=128 is fused: MMFT_ERR_UNSUPPORTED
+ * otherwise (callers then use two mmft_linear_* launches). */
+int mmft_mlp2_rows(const float* x1, long long ldx1, const int* rows, int n, const float* w1, long long ldw1,
+                   const float* b1, const float* w2, long long ldw2, const float* b2, int weights_kmajor,
+                   const float* mask, long long ldmask, float* hid_out, long long ldhid, float* out,
+                   long long ldout, int add_act, int relu_out, int K1, int HD, int D2, int device, void* stream);
 /* out[c] (+)= sum_r g[idx[r]][c]   (bias gradients); workspace >= mmft_colsum_workspace_bytes */
 long long mmft_colsum_workspace_bytes(int rows, int cols);
 int mmft_colsum(const float* g, const int* idx, long long ld, int rows, int cols, float* out, int accumulate,

@@ -1,0 +1,268 @@
+// Fused two-layer row kernel for the level-serial chain of the netlist sweep (K4 in SURVEY.md §2.4):
+//
+//   hid = mask ? (x1[rows] . W1) * (mask[rows] > 0)          (reverse sweep: dHn = (G W2g) * relu'(HN))
+//              : relu(x1[rows] . W1^T + b1)                  (forward: HN = relu(fc_cell_neigh.0(A)))
+//   out[rows] = epi(hid . W2 (+ b2))                         (forward: h = relu(h + ...); reverse: DA = ...)
+//
+// One workgroup owns 32 rows; the 32 x 256 hidden tile never leaves the CU (LDS), so a cell level costs one
+// launch instead of two GEMM launches and the hidden activations are not re-read from HBM.  Replaces the pair of
+// th.nn.Linear calls inside PathConv.apply_cell_func (reference src/model.py:138-146) and its autograd mirror.
+// Same fp32 MFMA fragments, LDS strides and k permutation as gemm_engine.h; 128 -> 256 -> 128 widths only
+// (the reference's PathConv defaults, src/model.py:48-51); other widths use the two-launch path.
+#include "gemm_engine.h"
+
+namespace mmft {
+
+constexpr int M2_BM = 32, M2_K1 = 128, M2_HD = 256, M2_D2 = 128, M2_BK = 32;
+
+struct Mlp2Args {
+  const float* x1;
+  long long ldx1;
+  const int* rows;
+  int n;
+  const float* w1;
+  long long ldw1;
+  const float* b1;
+  const float* w2;
+  long long ldw2;
+  const float* b2;
+  const float* mask;
+  long long ldmask;
+  float* hid_out;
+  long long ldhid;
+  float* out;
+  long long ldout;
+  int add_act;   // 1: out = act(out_old + acc + b2), 0: out = acc + b2
+  int relu_out;
+};
+
+// Weight panels are read from L2 ONCE per workgroup, at kernel entry, with every 16-byte load of both layers in
+// flight together (64 per thread = 256 VGPRs; the kernel runs one workgroup per CU, so the 512-entry register file
+// has room).  The K loops then only move registers -> LDS -> MFMA fragments: no global round trip sits on the
+// serial path of a level (the two-launch form paid one L2 round trip per 16-deep K step).
+template <bool KM, int N, int KT>   // tile kt of a weight with N output features; KT = number of 32-deep tiles
+struct WPanel {
+  static constexpr int PER = N * M2_BK / 4 / 256;
+  f32x4 r[KT][PER];
+  __device__ __forceinline__ void load(const float* w, long long ldw, int tid) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        int g = tid + i * 256;
+        if (KM) {
+          int kk = g / (N / 4), n4 = g % (N / 4);
+          r[kt][i] = *reinterpret_cast<const f32x4*>(w + (long long)(kt * M2_BK + kk) * ldw + n4 * 4);
+        } else {
+          int rr = g / (M2_BK / 4), k4 = g % (M2_BK / 4);
+          r[kt][i] = *reinterpret_cast<const f32x4*>(w + (long long)rr * ldw + kt * M2_BK + k4 * 4);
+        }
+      }
+  }
+  template <int KTI>
+  __device__ __forceinline__ void to_lds(float* dst, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int g = tid + i * 256;
+      if (KM) {
+        int kk = g / (N / 4), n4 = g % (N / 4);
+        *reinterpret_cast<f32x4*>(dst + kk * (N + 4) + n4 * 4) = r[KTI][i];
+      } else {
+        int rr = g / (M2_BK / 4), k4 = g % (M2_BK / 4);
+        *reinterpret_cast<f32x4*>(dst + rr * (M2_BK + 8) + k4 * 4) = r[KTI][i];
+      }
+    }
+  }
+};
+
+template <bool KM, int KTI, int NK>
+struct Phase1 {
+  template <class P>
+  static __device__ __forceinline__ void run(const P& pan, const float* xs, float* wb, int wsz, int tid, int lane, int wave,
+                                             f32x4 (&acc)[2][4]) {
+    constexpr int XS = M2_K1 + 8;
+    constexpr int WS = KM ? (M2_HD + 4) : (M2_BK + 8);
+    float* wt = wb + (KTI & 1) * wsz;
+    pan.template to_lds<KTI>(wt, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < M2_BK / 16; ++kb) {
+      float xf[2][4], wf[4][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) read_frag<false, XS>(xs, i * 16, KTI * (M2_BK / 16) + kb, lane, xf[i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) read_frag<KM, WS>(wt, wave * 64 + j * 16, kb, lane, wf[j]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][s], xf[i][s], acc[i][j], 0, 0, 0);
+    }
+    if constexpr (KTI + 1 < NK) Phase1<KM, KTI + 1, NK>::run(pan, xs, wb, wsz, tid, lane, wave, acc);
+  }
+};
+
+template <bool KM, int KTI, int NK>
+struct Phase2 {
+  template <class P>
+  static __device__ __forceinline__ void run(const P& pan, const float* hs, float* wb, int wsz, int tid, int lane, int wave,
+                                             f32x4 (&acc)[2][2]) {
+    constexpr int HS = M2_HD + 8;
+    constexpr int WS = KM ? (M2_D2 + 4) : (M2_BK + 8);
+    float* wt = wb + (KTI & 1) * wsz;
+    pan.template to_lds<KTI>(wt, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < M2_BK / 16; ++kb) {
+      float xf[2][4], wf[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) read_frag<false, HS>(hs, i * 16, KTI * (M2_BK / 16) + kb, lane, xf[i]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) read_frag<KM, WS>(wt, wave * 32 + j * 16, kb, lane, wf[j]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][s], xf[i][s], acc[i][j], 0, 0, 0);
+    }
+    if constexpr (KTI + 1 < NK) Phase2<KM, KTI + 1, NK>::run(pan, hs, wb, wsz, tid, lane, wave, acc);
+  }
+};
+
+template <bool KM>
+__global__ void __launch_bounds__(256, 1) mlp2_rows_kernel(Mlp2Args a) {
+  constexpr int XS = M2_K1 + 8;                       // 136: x1 tile, whole K resident
+  constexpr int HS = M2_HD + 8;                       // 264: hidden tile
+  constexpr int W1S = KM ? (M2_HD + 4) : (M2_BK + 8);
+  constexpr int W2S = KM ? (M2_D2 + 4) : (M2_BK + 8);
+  constexpr int W1SZ = KM ? M2_BK * W1S : M2_HD * W1S;
+  constexpr int W2SZ = KM ? M2_BK * W2S : M2_D2 * W2S;
+  constexpr int WSZ = W1SZ > W2SZ ? W1SZ : W2SZ;
+  __shared__ __attribute__((aligned(16))) float lds[M2_BM * XS + M2_BM * HS + 2 * WSZ];
+  float* xs = lds;
+  float* hs = lds + M2_BM * XS;
+  float* wb = hs + M2_BM * HS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * M2_BM;
+
+  // ---- every global load of the kernel is issued here: both weight panels and the gathered x1 rows
+  WPanel<KM, M2_HD, M2_K1 / M2_BK> p1;
+  WPanel<KM, M2_D2, M2_HD / M2_BK> p2;
+  p1.load(a.w1, a.ldw1, tid);
+  f32x4 xr[M2_BM * M2_K1 / 4 / 256];
+#pragma unroll
+  for (int i = 0; i < M2_BM * M2_K1 / 4 / 256; ++i) {
+    int g = tid + i * 256;
+    int r = g / (M2_K1 / 4), k4 = g % (M2_K1 / 4);
+    xr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (m0 + r < a.n) xr[i] = *reinterpret_cast<const f32x4*>(a.x1 + (long long)a.rows[m0 + r] * a.ldx1 + k4 * 4);
+  }
+  p2.load(a.w2, a.ldw2, tid);
+#pragma unroll
+  for (int i = 0; i < M2_BM * M2_K1 / 4 / 256; ++i) {
+    int g = tid + i * 256;
+    int r = g / (M2_K1 / 4), k4 = g % (M2_K1 / 4);
+    *reinterpret_cast<f32x4*>(xs + r * XS + k4 * 4) = xr[i];
+  }
+
+  // ---- phase 1: hid[32 x 256]; wave w owns hidden columns [64w, 64w+64)
+  f32x4 acc1[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  Phase1<KM, 0, M2_K1 / M2_BK>::run(p1, xs, wb, WSZ, tid, lane, wave, acc1);
+
+  // ---- epilogue 1: bias + ReLU, or ReLU mask from the saved forward hidden activations -> LDS (+ HBM)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int m = i * 16 + (lane & 15);
+      int nn = wave * 64 + j * 16 + (lane >> 4) * 4;
+      f32x4 v = acc1[i][j];
+      bool live = m0 + m < a.n;
+      long long row = live ? (long long)a.rows[m0 + m] : 0;
+      if (a.mask) {
+        f32x4 mk = {0.f, 0.f, 0.f, 0.f};
+        if (live) mk = *reinterpret_cast<const f32x4*>(a.mask + row * a.ldmask + nn);
+        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+        v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+      } else {
+        if (a.b1) {
+          v.x += a.b1[nn]; v.y += a.b1[nn + 1]; v.z += a.b1[nn + 2]; v.w += a.b1[nn + 3];
+        }
+        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+        v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(hs + m * HS + nn) = v;
+      if (a.hid_out && live) *reinterpret_cast<f32x4*>(a.hid_out + row * a.ldhid + nn) = v;
+    }
+  __syncthreads();   // hidden tile complete; phase 1's last weight tile no longer read
+
+  // ---- phase 2: out[32 x 128]; wave w owns output columns [32w, 32w+32)
+  f32x4 acc2[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  Phase2<KM, 0, M2_HD / M2_BK>::run(p2, hs, wb, WSZ, tid, lane, wave, acc2);
+
+  // ---- epilogue 2: row scatter by node id
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int m = i * 16 + (lane & 15);
+      if (m0 + m >= a.n) continue;
+      int nn = wave * 32 + j * 16 + (lane >> 4) * 4;
+      float* q = a.out + (long long)a.rows[m0 + m] * a.ldout + nn;
+      f32x4 v = acc2[i][j];
+      if (a.b2) {
+        v.x += a.b2[nn]; v.y += a.b2[nn + 1]; v.z += a.b2[nn + 2]; v.w += a.b2[nn + 3];
+      }
+      if (a.add_act) v += *reinterpret_cast<const f32x4*>(q);
+      if (a.relu_out) {
+        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+        v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(q) = v;
+    }
+}
+
+}  // namespace mmft
+
+using namespace mmft;
+
+extern "C" int mmft_mlp2_rows(const float* x1, long long ldx1, const int* rows, int n, const float* w1, long long ldw1,
+                              const float* b1, const float* w2, long long ldw2, const float* b2, int weights_kmajor,
+                              const float* mask, long long ldmask, float* hid_out, long long ldhid, float* out,
+                              long long ldout, int add_act, int relu_out, int K1, int HD, int D2, int device,
+                              void* stream) {
+  MMFT_REQUIRE(x1 && rows && w1 && w2 && out, "mlp2_rows: null pointer");
+  if (K1 != M2_K1 || HD != M2_HD || D2 != M2_D2) {
+    set_error("mlp2_rows: only %d -> %d -> %d is fused (got %d -> %d -> %d)", M2_K1, M2_HD, M2_D2, K1, HD, D2);
+    return MMFT_ERR_UNSUPPORTED;
+  }
+  MMFT_REQUIRE(n >= 0, "mlp2_rows: negative row count");
+  MMFT_REQUIRE(ldx1 % 4 == 0 && ldw1 % 4 == 0 && ldw2 % 4 == 0 && ldout % 4 == 0 && aligned16(x1) && aligned16(w1) &&
+                   aligned16(w2) && aligned16(out),
+               "mlp2_rows: operands must be 16-byte aligned");
+  MMFT_REQUIRE(!mask || (ldmask % 4 == 0 && aligned16(mask)), "mlp2_rows: mask alignment");
+  MMFT_REQUIRE(!hid_out || (ldhid % 4 == 0 && aligned16(hid_out)), "mlp2_rows: hid_out alignment");
+  MMFT_REQUIRE(weights_kmajor ? (ldw1 >= HD && ldw2 >= D2) : (ldw1 >= K1 && ldw2 >= HD), "mlp2_rows: weight strides");
+  if (n == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  hipStream_t st = (hipStream_t)stream;
+  Mlp2Args a{x1, ldx1, rows, n, w1, ldw1, b1, w2, ldw2, b2, mask, ldmask, hid_out, ldhid, out, ldout, add_act, relu_out};
+  ProfScope ps(weights_kmajor ? "mlp2_rows_kernel<KM>" : "mlp2_rows_kernel<MK>", 2.0 * n * ((double)K1 * HD + (double)HD * D2),
+               4.0 * n * ((double)K1 + 2.0 * HD + 2.0 * D2), st);
+  if (weights_kmajor) hipLaunchKernelGGL(mlp2_rows_kernel<true>, dim3(cdiv(n, M2_BM)), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(mlp2_rows_kernel<false>, dim3(cdiv(n, M2_BM)), dim3(256), 0, st, a);
+  return check_launch("mlp2_rows");
+}

@@ -21,5 +21,11 @@ def allreduce_sum_(flat, world_size):
     if world_size <= 1:
         return 1.0
     import torch.distributed as dist
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if flat.is_cuda and dist.get_backend() == 'gloo':
+        # rehearsal of the N>1 path on a box without RCCL peers: stage through the host
+        host = flat.detach().cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return 1.0 / world_size

@@ -129,6 +129,36 @@ def linear_wgrad(g, x, dw=None, gidx=None, xidx=None, rows=None, accumulate=Fals
     return dw
 
 
+def mlp2_fusable(K1, HD, D2):
+    return (K1, HD, D2) == (128, 256, 128)
+
+
+def mlp2_rows(x1, rows, w1, b1, w2, b2, out, kmajor=False, mask=None, hid_out=None, add_act=False, relu_out=False):
+    """Fused Linear-ReLU-Linear over the gathered rows `rows` (see mmft_mlp2_rows in include/mmft.h)."""
+    _rows2d(x1, 'x1'); _rows2d(w1, 'w1'); _rows2d(w2, 'w2'); _rows2d(out, 'out'); _idx(rows, 'rows')
+    if kmajor:
+        K1, HD = w1.shape
+        HD2, D2 = w2.shape
+    else:
+        HD, K1 = w1.shape
+        D2, HD2 = w2.shape
+    if HD2 != HD or x1.shape[1] != K1 or out.shape[1] != D2:
+        raise ValueError('mlp2_rows: inconsistent widths')
+    for t, nm, w in ((mask, 'mask', HD), (hid_out, 'hid_out', HD)):
+        if t is not None:
+            _rows2d(t, nm)
+            if t.shape[1] != w or t.shape[0] != x1.shape[0]:
+                raise ValueError(f'mlp2_rows: {nm} must be [rows of x1, {w}]')
+    if out.shape[0] != x1.shape[0]:
+        raise ValueError('mlp2_rows: out must have one row per row of x1 (scatter by node id)')
+    dev, st = lib.stream_args(x1)
+    lib.call('mmft_mlp2_rows', x1, x1.stride(0), rows, rows.numel(), w1, w1.stride(0), b1, w2, w2.stride(0), b2,
+             int(kmajor), mask, mask.stride(0) if mask is not None else 0, hid_out,
+             hid_out.stride(0) if hid_out is not None else 0, out, out.stride(0), int(add_act), int(relu_out),
+             K1, HD, D2, dev, st)
+    return out
+
+
 def colsum(g, out=None, idx=None, rows=None, accumulate=False):
     _rows2d(g, 'g')
     cols = g.shape[1]

@@ -96,6 +96,25 @@ def _w(p):
     return d if d.is_contiguous() else d.contiguous()
 
 
+def _cell_neigh_fwd(st, rows, w1g, b1g, w2g, b2g, act):
+    """h[rows] = act(h[rows] + fc_cell_neigh(A[rows])), HN[rows] saved: one fused launch when the widths allow."""
+    if ops.mlp2_fusable(st.D, st.Hd, st.D):
+        ops.mlp2_rows(st.A, rows, w1g, b1g, w2g, b2g, st.h, kmajor=False, hid_out=st.HN, add_act=True,
+                      relu_out=(act == ops.ACT_RELU))
+    else:
+        ops.linear_fwd(st.A, w1g, b1g, y=st.HN, xidx=rows, yidx=rows, act=ops.ACT_RELU)
+        ops.linear_fwd(st.HN, w2g, b2g, y=st.h, xidx=rows, yidx=rows, epi=ops.EPI_ADD_ACT, act=act)
+
+
+def _cell_neigh_bwd(st, rows, w1g, w2g):
+    """DA[rows] = ((G[rows] W2g) * relu'(HN[rows])) W1g."""
+    if ops.mlp2_fusable(st.D, st.Hd, st.D):
+        ops.mlp2_rows(st.G, rows, w2g, None, w1g, None, st.DA, kmajor=True, mask=st.HN)
+    else:
+        dhn = ops.linear_dgrad(st.G, w2g, gidx=rows, mask=st.HN, maskidx=rows)
+        ops.linear_dgrad(dhn, w1g, dx=st.DA, dxidx=rows)
+
+
 class LevelFn(torch.autograd.Function):
     """One PathConv.forward call. Inputs: chain token (+ the 12 MLP parameters at level 0)."""
 
@@ -118,8 +137,7 @@ class LevelFn(torch.autograd.Function):
                 ops.seg_softmax_sum_fwd(st.h, g.csr('in', 'cell'), rows, st.A, st.LSE)
                 ops.linear_fwd(st.cell_feat, w1c, b1c, y=st.HS, xidx=rows, yidx=rows, act=ops.ACT_RELU)
                 ops.linear_fwd(st.HS, w2c, b2c, y=st.h, xidx=rows, yidx=rows)
-                ops.linear_fwd(st.A, w1g, b1g, y=st.HN, xidx=rows, yidx=rows, act=ops.ACT_RELU)
-                ops.linear_fwd(st.HN, w2g, b2g, y=st.h, xidx=rows, yidx=rows, epi=ops.EPI_ADD_ACT, act=act)
+                _cell_neigh_fwd(st, rows, w1g, b1g, w2g, b2g, act)
         st.levels.append((level_id, rows))
         out = ops.gather_rows(st.h, tix) if tix.numel() else st.h.new_zeros((0, st.D))       # :213
         ctx.state, ctx.level_id, ctx.rows, ctx.tix = st, level_id, rows, tix
@@ -140,8 +158,7 @@ class LevelFn(torch.autograd.Function):
             ops.level_bwd_pull(st.G, st.h, rows, g.csr('out', 'net'), g.out_net_weight(), g.csr('out', 'cell'),
                                st.A, st.LSE, st.DA, relu=st.relu)
             if level_id % 2 == 0 and level_id > 0:
-                dhn = ops.linear_dgrad(st.G, w2g, gidx=rows, mask=st.HN, maskidx=rows)
-                ops.linear_dgrad(dhn, w1g, dx=st.DA, dxidx=rows)
+                _cell_neigh_bwd(st, rows, w1g, w2g)
         grads = [None] * ctx.nparams
         if level_id == 0:
             if ctx.nparams:
@@ -247,8 +264,7 @@ class SweepFn(torch.autograd.Function):
                 ops.seg_mean_add_act_fwd(st.h, in_net, rows, relu=st.relu)
             else:
                 ops.seg_softmax_sum_fwd(st.h, in_cell, rows, st.A, st.LSE)
-                ops.linear_fwd(st.A, w1g, b1g, y=st.HN, xidx=rows, yidx=rows, act=ops.ACT_RELU)
-                ops.linear_fwd(st.HN, w2g, b2g, y=st.h, xidx=rows, yidx=rows, epi=ops.EPI_ADD_ACT, act=act)
+                _cell_neigh_fwd(st, rows, w1g, b1g, w2g, b2g, act)
         ctx.state, ctx.tix, ctx.nparams = st, tix, len(params)
         return ops.gather_rows(st.h, tix) if tix.numel() else st.h.new_zeros((0, st.D))
 
@@ -267,8 +283,7 @@ class SweepFn(torch.autograd.Function):
                 continue
             ops.level_bwd_pull(st.G, st.h, rows, out_net, in_net_ptr, out_cell, st.A, st.LSE, st.DA, relu=st.relu)
             if level_id % 2 == 0 and level_id > 0:
-                dhn = ops.linear_dgrad(st.G, w2g, gidx=rows, mask=st.HN, maskidx=rows)
-                ops.linear_dgrad(dhn, w1g, dx=st.DA, dxidx=rows)
+                _cell_neigh_bwd(st, rows, w1g, w2g)
         grads = _batched_param_grads(st, P) if ctx.nparams else []
         st.bwd_active = False
         return (None, None, None, *grads)

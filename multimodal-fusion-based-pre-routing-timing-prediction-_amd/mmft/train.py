@@ -186,12 +186,13 @@ class GraphedTrainStep:
     """The whole mini-batch (forward, MSE, backward, fused Adam) captured ONCE as a HIP graph and replayed per
     step: the ~550 kernel launches of a step then cost no host time.  Per step the host only packs the sampled
     endpoints into one pinned int32 buffer (one H2D copy into a static device buffer) and uploads Adam's two
-    bias-correction scalars.  Requires a constant number of sampled paths per step and world_size == 1
-    (the multi-GPU path runs eagerly so that the RCCL all-reduce stays outside any capture)."""
+    bias-correction scalars.  Requires a constant number of sampled paths per step.  Under data parallelism the
+    graph holds forward + backward only; the RCCL all-reduce of the flat gradient and the fused Adam launch follow
+    the replay eagerly (two launches), so no collective is ever captured."""
 
     def __init__(self, ts, example_path_ids, warmup=3):
-        if ts.world_size != 1 or not ts.fused or ts.mode != 'sweep':
-            raise ValueError('GraphedTrainStep needs mode="sweep", the fused optimizer and a single rank')
+        if not ts.fused or ts.mode != 'sweep':
+            raise ValueError('GraphedTrainStep needs mode="sweep" and the fused optimizer')
         self.ts = ts
         b = ts.batch
         for _ in range(warmup):                       # optional eager optimizer steps before the capture
@@ -227,13 +228,19 @@ class GraphedTrainStep:
             loss = mse_loss(hats, arrival)
             ts.optim.zero_grad()
             loss.backward()
-            ts.optim.step_captured()
+            if ts.world_size == 1:
+                ts.optim.step_captured()
             self.loss, self.hats = loss.detach(), hats.detach()
         torch.cuda.synchronize()
 
     def step(self, path_ids_per_design):
         b = self.ts.batch
         sel = b.select(path_ids_per_design, static=self.static_idx)
-        self.ts.optim.prepare_step()
-        self.graph.replay()
+        if self.ts.world_size == 1:
+            self.ts.optim.prepare_step()
+            self.graph.replay()
+        else:
+            from .dist import allreduce_sum_
+            self.graph.replay()
+            self.ts.optim.step(gscale=allreduce_sum_(self.ts.optim.flat_grad, self.ts.world_size))
         return self.loss, self.hats, sel[4].tolist()

@@ -178,3 +178,30 @@ def test_level_bwd_pull_matches_autograd(dev):
     rows = torch.arange(0, 150, dtype=torch.int32, device=dev)
     ops.level_bwd_pull(G, h, rows, g.csr('out', 'net'), g.out_net_weight(), g.csr('out', 'cell'), A, LSE, DA, relu=True)
     assert rel_err(G[:150], relu_ref) < 5e-5
+
+
+@pytest.mark.parametrize('n', [1, 31, 32, 1000, 8064])
+def test_mlp2_rows_fused(dev, n):
+    """Fused Linear-ReLU-Linear over gathered rows (forward form and transposed-weight backward form)."""
+    N = 9000
+    A = T((N, 128), 1, dev); h0 = T((N, 128), 2, dev)
+    w1, b1 = T((256, 128), 3, dev, -0.1, 0.1), T((256,), 4, dev)
+    w2, b2 = T((128, 256), 5, dev, -0.1, 0.1), T((128,), 6, dev)
+    rows = torch.randperm(N)[:n].to(torch.int32).to(dev)
+    r = rows.long()
+    HN = torch.zeros((N, 256), device=dev)
+    h = h0.clone()
+    ops.mlp2_rows(A, rows, w1, b1, w2, b2, h, kmajor=False, hid_out=HN, add_act=True, relu_out=True)
+    hid = (A.double()[r] @ w1.double().t() + b1.double()).clamp_min(0)
+    ref = h0.double().clone()
+    ref[r] = (h0.double()[r] + hid @ w2.double().t() + b2.double()).clamp_min(0)
+    assert rel_err(h, ref) < TOL
+    assert rel_err(HN[r], hid) < TOL
+    # backward form: DA[rows] = ((G[rows] W2) * (HN[rows] > 0)) W1, weights read transposed
+    G = T((N, 128), 7, dev)
+    DA = torch.zeros((N, 128), device=dev)
+    ops.mlp2_rows(G, rows, w2, None, w1, None, DA, kmajor=True, mask=HN)
+    dh = (G.double()[r] @ w2.double()) * (HN.double()[r] > 0)
+    refd = torch.zeros((N, 128), dtype=torch.float64)
+    refd[r.cpu()] = (dh @ w1.double()).cpu()
+    assert rel_err(DA, refd) < TOL
