@@ -28,7 +28,7 @@ static int conv_fwd_launch(const float* x, const float* w, const float* bias, fl
   DenseMK wl{w, nullptr, K, N, (K % 4 == 0) && aligned16(w)};
   Epi epi{y, Co, nullptr, bias, nullptr, nullptr, 0, EPI_STORE, act, slope, 0, (Co % 4 == 0) && aligned16(y)};
   if (Ci % 4 == 0 && aligned16(x)) {
-    Im2colMK xl{x, H, W, Ci, KH, KW, pad, M};
+    Im2colMK xl{x, H, W, Ci, KH, KW, pad, M, make_decode(H, W, Ci, KW)};
     return launch_gemm(xl, wl, epi, M, N, K, 1, st);
   }
   Im2colMKScalar xl{x, H, W, Ci, KH, KW, pad, M};
@@ -492,7 +492,7 @@ int mmft_conv2d_wgrad(const float* x, const float* dy, float* dw, int Nimg, int 
           (N % 4 == 0) && aligned16(outp)};
   int rc;
   if (Ci % 4 == 0 && aligned16(x)) {
-    Im2colKM wl{x, H, W, Ci, KH, KW, pad, N};
+    Im2colKM wl{x, H, W, Ci, KH, KW, pad, N, make_decode(H, W, Ci, KW)};
     rc = launch_gemm(xl, wl, epi, M, N, K, splits, st);
   } else {
     Im2colKMScalar wl{x, H, W, Ci, KH, KW, pad, N};

@@ -95,12 +95,28 @@ struct DenseKM {
 };
 
 // NHWC implicit-GEMM A operand: X[m = pixel][k = (tap, ci)], C % 4 == 0
+// cheap index decode for the implicit-GEMM loaders: channel counts and image sizes on this path are powers of two,
+// so k -> (tap, ci) and pixel -> (img, y, x) are shifts (integer division is ~20 VALU instructions per 16-byte
+// load and made the small-channel convolutions VALU-bound); tap -> (ky, kx) uses a 16-bit reciprocal of KW.
+struct ConvDecode {
+  int cshift, wshift, hwshift, kwmagic;   // -1 where the size is not a power of two (then: plain division)
+};
+inline int log2_exact(int v) {
+  for (int s = 0; s < 31; ++s)
+    if ((1 << s) == v) return s;
+  return -1;
+}
+inline ConvDecode make_decode(int H, int W, int C, int KW) {
+  return ConvDecode{log2_exact(C), log2_exact(W), log2_exact(H * W), (65536 + KW - 1) / KW};
+}
+
 struct Im2colMK {
   static const char* name() { return "Im2colMK"; }
   static constexpr bool KMAJOR = false;
   const float* p;
   int H, W, C, KH, KW, pad;
   int rows;  // Nimg*H*W
+  ConvDecode dc;
   struct Ctx {
     int pix0, y, x;
   };
@@ -113,9 +129,9 @@ struct Im2colMK {
       return c;
     }
     int hw = H * W;
-    int img = m / hw;
+    int img = dc.hwshift >= 0 ? (m >> dc.hwshift) : m / hw;
     int rem = m - img * hw;
-    c.y = rem / W;
+    c.y = dc.wshift >= 0 ? (rem >> dc.wshift) : rem / W;
     c.x = rem - c.y * W;
     c.pix0 = img * hw;
     return c;
@@ -123,9 +139,9 @@ struct Im2colMK {
   __device__ __forceinline__ f32x4 load(const Ctx& c, int k, int kend) const {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (k >= kend) return v;
-    int tap = k / C;
+    int tap = dc.cshift >= 0 ? (k >> dc.cshift) : k / C;
     int ci = k - tap * C;
-    int ky = tap / KW;
+    int ky = (tap * dc.kwmagic) >> 16;          // exact for tap < 1000 (taps <= 81 here)
     int kx = tap - ky * KW;
     int yy = c.y + ky - pad, xx = c.x + kx - pad;
     if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) return v;
@@ -140,6 +156,7 @@ struct Im2colKM {
   const float* p;
   int H, W, C, KH, KW, pad;
   int cols;  // KH*KW*C
+  ConvDecode dc;
   struct Ctx {
     int dy, dx, ci;
   };
@@ -161,9 +178,9 @@ struct Im2colKM {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (k >= kend || c.ci < 0) return v;
     int hw = H * W;
-    int img = k / hw;
+    int img = dc.hwshift >= 0 ? (k >> dc.hwshift) : k / hw;
     int rem = k - img * hw;
-    int y = rem / W;
+    int y = dc.wshift >= 0 ? (rem >> dc.wshift) : rem / W;
     int x = rem - y * W;
     int yy = y + c.dy, xx = x + c.dx;
     if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) return v;
@@ -181,7 +198,7 @@ struct Im2colMKScalar {
   int rows;
   typedef Im2colMK::Ctx Ctx;
   __device__ __forceinline__ Ctx ctx(int m) const {
-    Im2colMK v{p, H, W, C, KH, KW, pad, rows};
+    Im2colMK v{p, H, W, C, KH, KW, pad, rows, ConvDecode{-1, -1, -1, 0}};
     return v.ctx(m);
   }
   __device__ __forceinline__ float one(const Ctx& c, int k, int kend) const {
@@ -491,7 +508,8 @@ inline int launch_gemm(const XL& xl, const WL& wl, const Epi& epi, int M, int N,
   };
   auto wgs = [&](int i) { return (long long)cdiv(M, cand[i][0]) * cdiv(N, cand[i][1]) * sp; };
   int pick = -1;
-  const long long want[3] = {1024, 512, 256};
+  // split-K launches reach the workgroup count through their slabs: keep the largest tile that gives >= 256
+  const long long want[3] = {splits > 1 ? 256 : 1024, splits > 1 ? 256 : 512, 256};
   for (int t = 0; t < 3 && pick < 0; ++t)
     for (int i = 0; i < ncand; ++i)
       if (fits(i) && wgs(i) >= want[t]) {

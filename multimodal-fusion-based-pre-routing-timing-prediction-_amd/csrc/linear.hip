@@ -261,7 +261,7 @@ int mmft_linear_dgrad(const float* g, const int* gidx, long long ldg, const floa
 
 static int wgrad_splits(int rows, int out, int in) {
   long long tiles = (long long)cdiv(out, 128) * cdiv(in, in <= 16 ? 16 : in <= 32 ? 32 : in <= 64 ? 64 : 128);
-  int want = (int)(512 / (tiles > 0 ? tiles : 1));
+  int want = (int)(768 / (tiles > 0 ? tiles : 1));
   int maxs = rows / 64;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;

@@ -49,7 +49,7 @@ class SweepState:
         self.LSE = self._buf('LSE', self.D)
         self.HS = self._buf('HS', self.Hd)
         self.HN = self._buf('HN', self.Hd)
-        self.G = self.DA = None
+        self.G = self.DA = self.DHN = None
         self.levels = []            # (level_id, rows) in forward order
         self.token = None
         self.next_level = 0
@@ -106,10 +106,16 @@ def _cell_neigh_fwd(st, rows, w1g, b1g, w2g, b2g, act):
         ops.linear_fwd(st.HN, w2g, b2g, y=st.h, xidx=rows, yidx=rows, epi=ops.EPI_ADD_ACT, act=act)
 
 
-def _cell_neigh_bwd(st, rows, w1g, w2g):
-    """DA[rows] = ((G[rows] W2g) * relu'(HN[rows])) W1g."""
+def _cell_neigh_bwd(st, rows, w1g, w2g, keep_dhn=False):
+    """DA[rows] = ((G[rows] W2g) * relu'(HN[rows])) W1g.  With keep_dhn the hidden gradient rows are also written to
+    st.DHN, so the batched weight-gradient pass does not recompute them."""
     if ops.mlp2_fusable(st.D, st.Hd, st.D):
-        ops.mlp2_rows(st.G, rows, w2g, None, w1g, None, st.DA, kmajor=True, mask=st.HN)
+        dhn_out = None
+        if keep_dhn:
+            if st.DHN is None:
+                st.DHN = st._buf('DHN', st.Hd)
+            dhn_out = st.DHN
+        ops.mlp2_rows(st.G, rows, w2g, None, w1g, None, st.DA, kmajor=True, mask=st.HN, hid_out=dhn_out)
     else:
         dhn = ops.linear_dgrad(st.G, w2g, gidx=rows, mask=st.HN, maskidx=rows)
         ops.linear_dgrad(dhn, w1g, dx=st.DA, dxidx=rows)
@@ -174,17 +180,22 @@ def _cat_rows(st, pred):
     return sel[0] if len(sel) == 1 else torch.cat(sel)
 
 
-def _mlp_grads(st, G, gidx, H, X, xidx, w2):
-    """Gradients of one Linear-ReLU-Linear MLP over the rows `gidx`: (dW1, db1, dW2, db2)."""
+def _mlp_grads(st, G, gidx, H, X, xidx, w2, dH_rows=None):
+    """Gradients of one Linear-ReLU-Linear MLP over the rows `gidx`: (dW1, db1, dW2, db2).
+    dH_rows: [N, Hd] buffer already holding the hidden gradients of those rows (from the level loop)."""
     dW2 = ops.linear_wgrad(G, H, gidx=gidx, xidx=gidx)
     db2 = ops.colsum(G, idx=gidx)
-    dH = ops.linear_dgrad(G, w2, gidx=gidx, mask=H, maskidx=gidx)
-    dW1 = ops.linear_wgrad(dH, X, xidx=xidx)
-    db1 = ops.colsum(dH)
+    if dH_rows is not None:
+        dW1 = ops.linear_wgrad(dH_rows, X, gidx=gidx, xidx=xidx)
+        db1 = ops.colsum(dH_rows, idx=gidx)
+    else:
+        dH = ops.linear_dgrad(G, w2, gidx=gidx, mask=H, maskidx=gidx)
+        dW1 = ops.linear_wgrad(dH, X, xidx=xidx)
+        db1 = ops.colsum(dH)
     return [dW1, db1, dW2, db2]
 
 
-def _batched_param_grads(st, P):
+def _batched_param_grads(st, P, dhn_ready=False):
     (w1c, b1c, w2c, b2c, w1n, b1n, w2n, b2n, w1g, b1g, w2g, b2g) = P
     rc = _cat_rows(st, lambda l: l % 2 == 0)
     rn = _cat_rows(st, lambda l: l % 2 == 1)
@@ -192,7 +203,8 @@ def _batched_param_grads(st, P):
     zeros = lambda ps: [torch.zeros_like(p) for p in ps]
     gc = _mlp_grads(st, st.G, rc, st.HS, st.cell_feat, rc, w2c) if rc is not None else zeros(P[0:4])
     gn = _mlp_grads(st, st.G, rn, st.HS, st.net_feat, rn, w2n) if rn is not None else zeros(P[4:8])
-    gg = _mlp_grads(st, st.G, rc2, st.HN, st.A, rc2, w2g) if rc2 is not None else zeros(P[8:12])
+    gg = _mlp_grads(st, st.G, rc2, st.HN, st.A, rc2, w2g, st.DHN if (dhn_ready and st.DHN is not None) else None) \
+        if rc2 is not None else zeros(P[8:12])
     return gc + gn + gg
 
 
@@ -283,8 +295,8 @@ class SweepFn(torch.autograd.Function):
                 continue
             ops.level_bwd_pull(st.G, st.h, rows, out_net, in_net_ptr, out_cell, st.A, st.LSE, st.DA, relu=st.relu)
             if level_id % 2 == 0 and level_id > 0:
-                _cell_neigh_bwd(st, rows, w1g, w2g)
-        grads = _batched_param_grads(st, P) if ctx.nparams else []
+                _cell_neigh_bwd(st, rows, w1g, w2g, keep_dhn=True)
+        grads = _batched_param_grads(st, P, dhn_ready=True) if ctx.nparams else []
         st.bwd_active = False
         return (None, None, None, *grads)
 
