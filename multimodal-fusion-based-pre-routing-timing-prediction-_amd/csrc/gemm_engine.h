@@ -19,6 +19,7 @@
 // Exact fp32: v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain (guide §3 "FP32-input MFMA").
 #pragma once
 #include "common.h"
+#include <stdlib.h>
 
 namespace mmft {
 
@@ -531,6 +532,20 @@ inline int launch_gemm(const XL& xl, const WL& wl, const Epi& epi, int M, int N,
   if (splits <= 1 && K >= 64 && K <= 512 && (long long)M * N <= (1ll << 23) && ncap >= 64 && mcap >= 32) {
     launch_cfg<TileCfg<32, 64, 64, 2, 2>>(xl, wl, epi, M, N, K, splits, st);
     return check_launch("gemm_f32");
+  }
+  // tuning hook (tools/bench_gemm.py): MMFT_GEMM_FORCE=<bm>x<bn>x<bk> forces one of the wide-K-step tiles
+  if (const char* f = getenv("MMFT_GEMM_FORCE")) {
+    int fbm = 0, fbn = 0, fbk = 0;
+    if (sscanf(f, "%dx%dx%d", &fbm, &fbn, &fbk) == 3) {
+      if (fbm == 128 && fbn == 128 && fbk == 32) { launch_cfg<TileCfg<128, 128, 32, 2, 2>>(xl, wl, epi, M, N, K, splits, st); return check_launch("gemm_f32"); }
+      if (fbm == 128 && fbn == 64 && fbk == 32) { launch_cfg<TileCfg<128, 64, 32, 2, 2>>(xl, wl, epi, M, N, K, splits, st); return check_launch("gemm_f32"); }
+      if (fbm == 64 && fbn == 128 && fbk == 32) { launch_cfg<TileCfg<64, 128, 32, 2, 2>>(xl, wl, epi, M, N, K, splits, st); return check_launch("gemm_f32"); }
+      if (fbm == 64 && fbn == 64 && fbk == 32) { launch_cfg<TileCfg<64, 64, 32, 2, 2>>(xl, wl, epi, M, N, K, splits, st); return check_launch("gemm_f32"); }
+      if (fbm == 64 && fbn == 64 && fbk == 64) { launch_cfg<TileCfg<64, 64, 64, 2, 2>>(xl, wl, epi, M, N, K, splits, st); return check_launch("gemm_f32"); }
+      if (fbm == 128 && fbn == 64 && fbk == 16) { launch_cfg<TileCfg<128, 64, 16, 2, 2>>(xl, wl, epi, M, N, K, splits, st); return check_launch("gemm_f32"); }
+      if (fbm == 64 && fbn == 128 && fbk == 16) { launch_cfg<TileCfg<64, 128, 16, 2, 2>>(xl, wl, epi, M, N, K, splits, st); return check_launch("gemm_f32"); }
+      if (fbm == 64 && fbn == 64 && fbk == 16) { launch_cfg<TileCfg<64, 64, 16, 2, 2>>(xl, wl, epi, M, N, K, splits, st); return check_launch("gemm_f32"); }
+    }
   }
 #define MMFT_GO(BM, BN, WM, WN) launch_cfg<TileCfg<BM, BN, 16, WM, WN>>(xl, wl, epi, M, N, K, splits, st)
   switch (cand[pick][0] * 1000 + cand[pick][1]) {
