@@ -87,7 +87,26 @@ __global__ void __launch_bounds__(256) masked_fc_bwd_kernel(const int* __restric
     long long cell = (long long)b * P + p;
     f32x4 S = {0.f, 0.f, 0.f, 0.f};
     if (valid) {
-      for (int e = cptr[cell]; e < cptr[cell + 1]; ++e)
+      // four covering paths per trip: their index -> batch-row -> gradient-row load chains overlap.
+      // Summation order stays fixed (e ascending, duplicates of a path in batch order): reproducible.
+      int e = cptr[cell], e1 = cptr[cell + 1];
+      for (; e + 4 <= e1; e += 4) {
+        int t0 = first[cpaths[e]], t1 = first[cpaths[e + 1]], t2 = first[cpaths[e + 2]], t3 = first[cpaths[e + 3]];
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 r0 = t0 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t0 * Dout + c4 * 4) : z;
+        f32x4 r1 = t1 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t1 * Dout + c4 * 4) : z;
+        f32x4 r2 = t2 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t2 * Dout + c4 * 4) : z;
+        f32x4 r3 = t3 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t3 * Dout + c4 * 4) : z;
+        S += r0;
+        if (t0 >= 0) for (int t = next[t0]; t >= 0; t = next[t]) S += *reinterpret_cast<const f32x4*>(gout + (long long)t * Dout + c4 * 4);
+        S += r1;
+        if (t1 >= 0) for (int t = next[t1]; t >= 0; t = next[t]) S += *reinterpret_cast<const f32x4*>(gout + (long long)t * Dout + c4 * 4);
+        S += r2;
+        if (t2 >= 0) for (int t = next[t2]; t >= 0; t = next[t]) S += *reinterpret_cast<const f32x4*>(gout + (long long)t * Dout + c4 * 4);
+        S += r3;
+        if (t3 >= 0) for (int t = next[t3]; t >= 0; t = next[t]) S += *reinterpret_cast<const f32x4*>(gout + (long long)t * Dout + c4 * 4);
+      }
+      for (; e < e1; ++e)
         for (int t = first[cpaths[e]]; t >= 0; t = next[t])
           S += *reinterpret_cast<const f32x4*>(gout + (long long)t * Dout + c4 * 4);
       dw += S * f[cell];
