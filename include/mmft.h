@@ -200,10 +200,12 @@ int mmft_masked_fc_fwd(const int* mask_indptr, const int* mask_cols, const int* 
  * row with the same path (-1: none), so duplicates from oversampling are summed in batch order.
  *   S = sum_{t : p in mask(paths[t]), design(t) = b} gout[t][:]
  *   dwT[p][:] = sum_b f[b][p] * S      (transposed weight gradient, [P][Dout])
- *   df[b][p]  = sum_c w T[p][c] * S[c]                                      */
+ *   df[b][p]  = sum_c wT[p][c] * S[c]
+ * For B > 1 the designs run in parallel block columns; workspace >= B*P*Dout*4 bytes holds their dwT slabs. */
 int mmft_masked_fc_bwd(const int* csc_indptr, const int* csc_paths, const int* first, const int* next,
                        const float* gout, const float* f, const float* wT, float* dwT, float* df,
-                       int B, int P, int Dout, int device, void* stream);
+                       int B, int P, int Dout, float* workspace, long long workspace_bytes,
+                       int device, void* stream);
 /* loss = mean((pred-target)^2); grad[i] = 2*(pred[i]-target[i])/n   (single workgroup, n <= 2^24) */
 int mmft_mse_fwd_bwd(const float* pred, const float* target, int n, float* loss, float* grad,
                      int device, void* stream);

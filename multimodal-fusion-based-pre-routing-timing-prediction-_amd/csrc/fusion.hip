@@ -7,6 +7,9 @@ namespace mmft {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// defined in linear.hip: deterministic fixed-order sum of slabs
+int launch_slab_reduce(const float* slabs, int splits, long long elems, float* out, int accumulate, hipStream_t st);
+
 __global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R,
                                                         int C) {
   __shared__ float tile[32][33];
@@ -83,7 +86,7 @@ __global__ void __launch_bounds__(256) masked_fc_bwd_kernel(const int* __restric
   const bool valid = lc < cells_per_block && p < P;
   f32x4 w = {0.f, 0.f, 0.f, 0.f}, dw = {0.f, 0.f, 0.f, 0.f};
   if (valid) w = *reinterpret_cast<const f32x4*>(wT + (long long)p * Dout + c4 * 4);
-  for (int b = 0; b < B; ++b) {
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
     long long cell = (long long)b * P + p;
     f32x4 S = {0.f, 0.f, 0.f, 0.f};
     if (valid) {
@@ -120,7 +123,8 @@ __global__ void __launch_bounds__(256) masked_fc_bwd_kernel(const int* __restric
       df[cell] = d;
     }
   }
-  if (valid) *reinterpret_cast<f32x4*>(dwT + (long long)p * Dout + c4 * 4) = dw;
+  // one slab of dwT per blockIdx.y (summed over the designs this block column handled)
+  if (valid) *reinterpret_cast<f32x4*>(dwT + ((long long)blockIdx.y * P + p) * Dout + c4 * 4) = dw;
 }
 
 __global__ void __launch_bounds__(1024) mse_kernel(const float* __restrict__ pred, const float* __restrict__ target, int n,
@@ -190,18 +194,32 @@ int mmft_masked_fc_fwd(const int* mask_indptr, const int* mask_cols, const int* 
 }
 
 int mmft_masked_fc_bwd(const int* csc_indptr, const int* csc_paths, const int* first, const int* next, const float* gout,
-                       const float* f, const float* wT, float* dwT, float* df, int B, int P, int Dout, int device,
-                       void* stream) {
+                       const float* f, const float* wT, float* dwT, float* df, int B, int P, int Dout, float* workspace,
+                       long long workspace_bytes, int device, void* stream) {
   MMFT_REQUIRE(csc_indptr && first && next && gout && f && wT && dwT && df, "masked_fc_bwd: null pointer");
   MMFT_REQUIRE(B > 0 && P > 0 && Dout >= 4 && Dout <= 1024 && Dout % 4 == 0,
                "masked_fc_bwd: Dout must be a multiple of 4 in [4, 1024]");
   MMFT_REQUIRE(aligned16(gout) && aligned16(wT) && aligned16(dwT), "masked_fc_bwd: 16-byte alignment");
   DeviceGuard dg(device);
   int groups = Dout / 4, cpb = 256 / groups;
-  ProfScope ps("masked_fc_bwd_kernel", 0.0, 0.0, (hipStream_t)stream);
-  hipLaunchKernelGGL(masked_fc_bwd_kernel, dim3(cdiv(P, cpb)), dim3(256), 0, (hipStream_t)stream, csc_indptr, csc_paths,
-                     first, next, gout, f, wT, dwT, df, B, P, Dout);
-  return check_launch("masked_fc_bwd");
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 1) {
+    ProfScope ps("masked_fc_bwd_kernel", 0.0, 0.0, st);
+    hipLaunchKernelGGL(masked_fc_bwd_kernel, dim3(cdiv(P, cpb), 1), dim3(256), 0, st, csc_indptr, csc_paths, first, next,
+                       gout, f, wT, dwT, df, B, P, Dout);
+    return check_launch("masked_fc_bwd");
+  }
+  // one block column per design: B-fold parallelism; the per-design dwT slabs are summed in fixed order
+  long long need = (long long)B * P * Dout * 4;
+  MMFT_REQUIRE(workspace && workspace_bytes >= need && aligned16(workspace), "masked_fc_bwd: workspace too small");
+  {
+    ProfScope ps("masked_fc_bwd_kernel", 0.0, 0.0, st);
+    hipLaunchKernelGGL(masked_fc_bwd_kernel, dim3(cdiv(P, cpb), B), dim3(256), 0, st, csc_indptr, csc_paths, first, next,
+                       gout, f, wT, workspace, df, B, P, Dout);
+  }
+  int rc = check_launch("masked_fc_bwd");
+  if (rc) return rc;
+  return launch_slab_reduce(workspace, B, (long long)P * Dout, dwT, 0, st);
 }
 
 int mmft_mse_fwd_bwd(const float* pred, const float* target, int n, float* loss, float* grad, int device, void* stream) {

@@ -134,8 +134,9 @@ class MaskedFcFn(torch.autograd.Function):
         B = pm.masks.B
         dwT = torch.empty_like(wT)
         df = torch.empty(B * P, dtype=torch.float32, device=f.device)
+        ws = lib.workspace(f.device, B * P * Dout * 4 if B > 1 else 0)
         lib.call('mmft_masked_fc_bwd', pm.masks.csc_indptr, pm.masks.csc_paths, pm.first, pm.next, g, f, wT, dwT, df,
-                 B, P, Dout, dev, st)
+                 B, P, Dout, ws, ws.numel() * 4, dev, st)
         dw = None
         if ctx.needs_input_grad[1]:
             dw = torch.empty((Dout, P), dtype=torch.float32, device=f.device)
