@@ -229,6 +229,15 @@ def main():
                                    tflops=(r['flops'] / (r['ms'] * 1e-3) / 1e12) if r['ms'] > 0 else 0.0)
                               for r in rows[:5]])
 
+    # accuracy half of BASELINE.json's metric: endpoint-slack MAE on a held-out synthetic design after the steps above
+    heldout_mae = None
+    if rank == 0:
+        from mmft.evaluate import validate
+        held = synth_design(N=args.nodes, L=args.levels, tile=args.tile, seed=9294 + 100003)
+        ev = TrainStep(pmodel, cnn, [held], dev, mode=args.mode, overlap=False, with_optimizer=False)
+        heldout_mae = validate(ev)
+        log(f"held-out design: slack MAE {heldout_mae['endpoint_slack_mae']:.4f}, R2 {heldout_mae['r2']:.4f}")
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log('timing the CPU oracle (bounded sample)')
@@ -263,6 +272,8 @@ def main():
             'nodes_per_s': value * args.nodes,
             'pixels_per_s': value * args.tile * args.tile,
             'train_mae_last_step': mae,
+            'heldout_eval': dict(steps_trained=ts.optim.step_count, **{k: heldout_mae[k] for k in
+                                 ('endpoint_slack_mae', 'r2', 'loss', 'f1', 'n')}) if heldout_mae else None,
             'loss_last_step': float(loss),
             'roofline': roofline,
             'cpu_baseline': cpu,

@@ -209,6 +209,12 @@ int mmft_masked_fc_bwd(const int* csc_indptr, const int* csc_paths, const int* f
 /* loss = mean((pred-target)^2); grad[i] = 2*(pred[i]-target[i])/n   (single workgroup, n <= 2^24) */
 int mmft_mse_fwd_bwd(const float* pred, const float* target, int n, float* loss, float* grad,
                      int device, void* stream);
+/* Evaluation sums of validate() / test() (src/train.py:230-278, src/test.py:211-216,231-300) in one pass, fp64:
+ * out[0..9] = n, sum y, sum y^2, sum (p-y)^2, sum |p-y|, sum |p-y|/|y| (MAPE numerator, y != 0),
+ *             tp, fp, tn, fn   with predicted critical = (required - p) < 0 (judge_critical, src/train.py:391-395)
+ *             and actual critical = label != 0.   Single workgroup, n <= 2^24. */
+int mmft_eval_sums(const float* pred, const float* arrival, const float* required, const float* label,
+                   int n, double* out, int device, void* stream);
 /* one Adam step over flat buffers, same operation order as torch.optim.Adam (amsgrad=False):
  * g += wd*p; m = lerp(m, g, 1-b1); v = b2*v + (1-b2)*g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
  * gscale multiplies the gradient first (1/world_size after a sum all-reduce) */

@@ -146,6 +146,40 @@ __global__ void __launch_bounds__(1024) mse_kernel(const float* __restrict__ pre
   if (threadIdx.x == 0) loss[0] = (float)(red[0] / (double)n);
 }
 
+__global__ void __launch_bounds__(1024) eval_sums_kernel(const float* __restrict__ pred, const float* __restrict__ y,
+                                                         const float* __restrict__ req, const float* __restrict__ label,
+                                                         int n, double* __restrict__ out) {
+  __shared__ double red[10][1024 / 64];
+  double a[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    double p = pred[i], t = y[i];
+    double d = p - t;
+    a[0] += 1.0;
+    a[1] += t;
+    a[2] += t * t;
+    a[3] += d * d;
+    a[4] += fabs(d);
+    if (t != 0.0) a[5] += fabs(d) / fabs(t);
+    bool pc = ((double)req[i] - p) < 0.0, ac = label[i] != 0.f;
+    a[6] += (pc && ac) ? 1.0 : 0.0;
+    a[7] += (pc && !ac) ? 1.0 : 0.0;
+    a[8] += (!pc && !ac) ? 1.0 : 0.0;
+    a[9] += (!pc && ac) ? 1.0 : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    double v = a[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 10) {
+    double s = 0.0;
+    for (int w = 0; w < 1024 / 64; ++w) s += red[threadIdx.x][w];
+    out[threadIdx.x] = s;
+  }
+}
+
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float step_size, float beta1,
                                                    float beta2, float eps, float wd, float bc2_sqrt, float gscale,
@@ -227,6 +261,14 @@ int mmft_mse_fwd_bwd(const float* pred, const float* target, int n, float* loss,
   DeviceGuard dg(device);
   hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, target, n, loss, grad);
   return check_launch("mse_fwd_bwd");
+}
+
+int mmft_eval_sums(const float* pred, const float* arrival, const float* required, const float* label, int n, double* out,
+                   int device, void* stream) {
+  MMFT_REQUIRE(pred && arrival && required && label && out && n > 0 && n <= (1 << 24), "eval_sums: bad args");
+  DeviceGuard dg(device);
+  hipLaunchKernelGGL(eval_sums_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, arrival, required, label, n, out);
+  return check_launch("eval_sums");
 }
 
 int mmft_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,

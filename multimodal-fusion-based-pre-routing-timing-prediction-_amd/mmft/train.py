@@ -102,7 +102,7 @@ class DesignBatch:
 
 class TrainStep:
     def __init__(self, pmodel, cnn, designs, device, lr=1e-3, weight_decay=0.0, fused_optimizer=True, world_size=1,
-                 mode='sweep', overlap=True):
+                 mode='sweep', overlap=True, with_optimizer=True):
         """mode='dropin': per-level model() calls exactly as src/train.py:490-511;
         mode='sweep': PathModel.forward_sweep, same arithmetic with level-invariant work hoisted."""
         assert mode in ('dropin', 'sweep')
@@ -114,10 +114,12 @@ class TrainStep:
         self.batch = DesignBatch(designs, device, pmodel.gnn.out_feat_dim if pmodel.gnn is not None else 128)
         self.world_size = world_size
         if cnn is not None and hasattr(cnn, 'set_per_sample_stats'):
-            cnn.set_per_sample_stats(self.batch.B > 1)
+            cnn.set_per_sample_stats(True)      # per-image statistics == the reference's one-image batches, any B
         params = trainable_parameters(pmodel, cnn)
         self.fused = fused_optimizer
-        if fused_optimizer:
+        if not with_optimizer:                  # evaluation-only harness (mmft.evaluate.validate): shares the modules
+            self.optim = None
+        elif fused_optimizer:
             self.optim = FlatAdam(params, lr=lr, weight_decay=weight_decay)
         else:
             self.optim = torch.optim.Adam(params, lr, weight_decay=weight_decay)     # src/train.py:431-435

@@ -374,3 +374,52 @@ def test_graphed_step_equals_eager(dev):
         out[kind] = (losses, hats.clone(), {k: v.clone() for k, v in pmodel.state_dict().items()})
     np.testing.assert_allclose(out['graph'][0], out['eager'][0], rtol=2e-4)
     close(out['graph'][1], out['eager'][1], 2e-4, 'hats after 6 steps')
+
+
+def test_eval_metrics_match_reference_formulas(dev):
+    """mmft.evaluate (one sums kernel) against the reference's metric formulas computed with torch on the host."""
+    from mmft.evaluate import eval_sums, metrics_from_sums
+    torch.manual_seed(0)
+    n = 5000
+    y = torch.rand(n) * 2 + 0.1
+    p = y + 0.2 * torch.randn(n)
+    req = torch.full((n,), 1.2)
+    lab = ((req - y) < 0).float()
+    m = metrics_from_sums(eval_sums(p.to(dev), y.to(dev), req.to(dev), lab.to(dev)).cpu().tolist())
+    pd, yd = p.double(), y.double()
+    assert abs(m['loss'] - float(((pd - yd) ** 2).mean())) < 1e-9
+    assert abs(m['r2'] - float(R.r2_score(pd, yd))) < 1e-9
+    assert abs(m['endpoint_slack_mae'] - float((pd - yd).abs().mean())) < 1e-9
+    pc = R.judge_critical(p, req)                              # src/train.py:391-395
+    tp = int(((pc != 0) & (lab != 0)).sum()); fn = int(((pc == 0) & (lab != 0)).sum())
+    fp = int(((pc != 0) & (lab == 0)).sum()); tn = int(((pc == 0) & (lab == 0)).sum())
+    assert (m['tp'], m['fp'], m['tn'], m['fn']) == (tp, fp, tn, fn)
+    assert abs(m['recall'] - tp / (tp + fn)) < 1e-12 and abs(m['precision'] - tp / (tp + fp)) < 1e-12
+
+
+def test_training_trajectory_vs_oracle(dev):
+    """20 Adam steps on one small design: HIP path vs the fp64 CPU oracle, same init / data / batch order.
+    Loss trajectory and held-out endpoint-slack MAE must track (the accuracy half of BASELINE.json's metric)."""
+    from mmft.synth import synth_design
+    from mmft.train import build_models, TrainStep
+    from mmft.evaluate import validate
+    d = synth_design(N=2048, L=12, tile=32, seed=41, end_frac=0.5)
+    pmodel, cnn = build_models(map_size=d.map_size, device=dev, seed=9294)
+    pm_state = {k: v.detach().cpu().clone() for k, v in pmodel.state_dict().items()}
+    pc_state = {k: v.detach().cpu().clone() for k, v in cnn.state_dict().items()}
+    oracle = R.OracleTrainer(pm_state, pc_state, dtype=torch.float64)
+    csr = R.design_csr(d)
+    ts = TrainStep(pmodel, cnn, [d], dev)
+    rng = np.random.default_rng(0)
+    lo, lg = [], []
+    for it in range(20):
+        ids = rng.permutation(d.num_paths)[:64].tolist()
+        l_o, _, _ = oracle.step(d, csr, ids)
+        l_g, _, _ = ts.step([ids])
+        lo.append(l_o); lg.append(float(l_g))
+    np.testing.assert_allclose(lg, lo, rtol=2e-2, atol=1e-4)   # fp32 vs fp64 trajectories, losses down to 1e-3
+    assert lo[-1] < lo[0]                                       # it learns
+    m = validate(ts)
+    hats_o, tl_o, _ = oracle.forward(d, csr, list(range(d.num_paths)))
+    mae_o = float((hats_o.detach() - torch.from_numpy(d.arrival_time).double()[torch.tensor(tl_o)].squeeze(-1)).abs().mean())
+    assert abs(m["endpoint_slack_mae"] - mae_o) < 2e-2 * max(mae_o, 1e-6) + 1e-4
