@@ -156,3 +156,29 @@ def test_full_size_properties(dev):
     h4, e4, g4, l4 = run('dropin', ident)                                      # per-level API == whole-sweep entry
     assert e4.tolist() == e1.tolist() and rel_err(h4, h1) < 1e-5 and rel_err(g4, g1) < 1e-4
     assert np.isfinite(l1) and float(g1.abs().max()) > 0
+
+
+@pytest.mark.parametrize('cfg', ['C', 'E'])
+def test_large_configs_run_and_are_deterministic(dev, cfg):
+    """BASELINE configs[2] / [4] shapes on one GPU: asap7-like 300k-node design and the 1M-node irregular-fan-in
+    stress netlist, 512x512 tiles (map 256^2, P = 65 536).  Too large for the CPU oracle inside a test, so:
+    finite results, bitwise reproducibility of predictions and gradients, drop-in == whole-sweep predictions."""
+    from mmft.synth import config_design
+    d = config_design(cfg)
+    assert d.tile == 512 and d.map_size == 256
+    ids = np.random.default_rng(0).permutation(d.num_paths)[:1350].tolist()
+    res = []
+    for mode in ('sweep', 'sweep', 'dropin'):
+        pmodel, cnn = build_models(map_size=d.map_size, device=dev, seed=9294)
+        ts = TrainStep(pmodel, cnn, [d], dev, mode=mode, overlap=False)
+        hats, ends_d, ends_h = ts.forward([ids])
+        loss = mse_loss(hats, ts.batch.arrival[ends_d.long()].squeeze(-1))
+        ts.optim.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((hats.detach().clone(), ts.optim.flat_grad.clone(), float(loss.detach())))
+        del ts, pmodel, cnn
+        torch.cuda.empty_cache()
+    assert np.isfinite(res[0][2]) and float(res[0][1].abs().max()) > 0
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert rel_err(res[2][0], res[0][0]) < 1e-5 and rel_err(res[2][1], res[0][1]) < 1e-4

@@ -131,3 +131,44 @@ def test_design_batch_select_order():
     assert counts.sum() == 6 and len(b.level_nodes) == 8
     first, nxt = b.links
     assert first.numel() == b.path_off[-1] and nxt.numel() == 6
+
+
+def test_design_record_roundtrip_and_reference_tuple_converter(tmp_path):
+    """On-disk record: npz round trip, and conversion from the reference's 7-tuple layout
+    (src/generate_data.py:50-54) through duck-typed heterograph accessors."""
+    from mmft.record import save_design, load_design, from_reference_tuple
+    d = synth_design(N=512, L=8, tile=16, seed=3, end_frac=0.5)
+    f = str(tmp_path / 'd.npz')
+    save_design(f, d)
+    e = load_design(f)
+    assert e.N == d.N and e.L == d.L and e.map_size == d.map_size
+    for k in ('net_src', 'cell_dst', 'cell_feat', 'mask_cols', 'mask_indptr', 'path2endpoint', 'image', 'arrival_time'):
+        assert np.array_equal(getattr(e, k), getattr(d, k)), k
+    assert all(np.array_equal(a, b) for a, b in zip(e.levels, d.levels))
+    assert all(np.array_equal(a, b) for a, b in zip(e.level_targets, d.level_targets))
+
+    class FakeHetero:                                      # the accessors of a DGL heterograph the converter touches
+        def __init__(s):
+            pad = lambda a, k: np.concatenate([a, np.zeros((a.shape[0], k), a.dtype)], 1)
+            s.ndata = {'cell_feat': torch.from_numpy(pad(d.cell_feat, 6)), 'net_feat': torch.from_numpy(pad(d.net_feat, 1)),
+                       'arrival_time': torch.from_numpy(d.arrival_time), 'required_time': torch.from_numpy(d.required_time),
+                       'label': torch.from_numpy(d.label), 'end': torch.from_numpy(d.is_end)}
+
+        def number_of_nodes(s):
+            return d.N
+
+        def edges(s, etype):
+            a, b = (d.net_src, d.net_dst) if etype == 'net' else (d.cell_src, d.cell_dst)
+            return torch.from_numpy(a), torch.from_numpy(b)
+
+    rows = np.repeat(np.arange(d.num_paths), np.diff(d.mask_indptr))
+    masks = torch.sparse_coo_tensor(np.stack([rows, d.mask_cols]), torch.ones(rows.shape[0], dtype=torch.int64),
+                                    (d.num_paths, d.map_size ** 2))
+    rec = (FakeHetero(), d.topo_levels(), masks, {p: int(l) for p, l in enumerate(d.path2level)},
+           {p: int(v) for p, v in enumerate(d.path2endpoint)}, d.critical_paths.tolist(), d.image)
+    c = from_reference_tuple(rec, feat_reduce=(6, 1), map_size=d.map_size)
+    assert c.N == d.N and c.L == d.L and c.tile == d.tile
+    for k in ('net_src', 'net_dst', 'cell_src', 'cell_dst', 'cell_feat', 'net_feat', 'mask_indptr', 'mask_cols',
+              'path2level', 'path2endpoint', 'arrival_time', 'label'):
+        assert np.array_equal(getattr(c, k), getattr(d, k)), k
+    assert all(np.array_equal(a, b) for a, b in zip(c.levels, d.levels))
