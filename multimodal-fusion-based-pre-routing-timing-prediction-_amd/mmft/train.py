@@ -224,7 +224,8 @@ class GraphedTrainStep:
         ts.optim.ensure_scalars()          # buffers only: capturing records the launch, it does not take a step
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: RCCL's watchdog thread may query events while this thread captures
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             hats, ends_d, _ = ts.forward(None, _sel=sel)
             arrival = b.arrival[ends_d.long()].squeeze(-1)
             loss = mse_loss(hats, arrival)
