@@ -120,6 +120,16 @@ int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows,
                         const int* out_cell_indptr, const int* out_cell_indices,
                         const float* A, const float* LSE, const float* DA, int relu,
                         int device, void* stream);
+/* Persistent forward sweep: ONE launch for levels 1..L-1 of a mini-batch (the L per-level PathConv.forward calls of
+ * src/train.py:490-511).  h must hold the *_self MLP outputs of every node (level 0 already activated); levels
+ * are separated by an in-kernel grid barrier (agent-scope release/acquire, bounded spin).  level_ptr[L+1] /
+ * level_rows: node ids level-major; counter / error_flag: one device word each (zeroed by the call; error_flag
+ * becomes 1 if a barrier wait ran out, in which case h is incomplete).  D = 128, HD = 256 only. */
+int mmft_sweep_fwd_persistent(float* h, float* A, float* LSE, float* HN, const int* in_net_indptr,
+                              const int* in_net_indices, const int* in_cell_indptr, const int* in_cell_indices,
+                              const int* level_ptr, const int* level_rows, int L, const float* w1, const float* b1,
+                              const float* w2, const float* b2, int relu, int D, int HD, int max_level_rows,
+                              unsigned* counter, int* error_flag, int device, void* stream);
 /* dst[i] = src[idx[i]]  /  dst[idx[i]] += src[i] (atomic, duplicates allowed: src/train.py:377-380) */
 int mmft_gather_rows(const float* src, long long lds, const int* idx, int n, int D, float* dst, long long ldd,
                      int device, void* stream);

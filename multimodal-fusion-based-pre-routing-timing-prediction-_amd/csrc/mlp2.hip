@@ -9,129 +9,9 @@
 // th.nn.Linear calls inside PathConv.apply_cell_func (reference src/model.py:138-146) and its autograd mirror.
 // Same fp32 MFMA fragments, LDS strides and k permutation as gemm_engine.h; 128 -> 256 -> 128 widths only
 // (the reference's PathConv defaults, src/model.py:48-51); other widths use the two-launch path.
-#include "gemm_engine.h"
+#include "mlp2_core.h"
 
 namespace mmft {
-
-constexpr int M2_BM = 32, M2_K1 = 128, M2_HD = 256, M2_D2 = 128, M2_BK = 32;
-
-struct Mlp2Args {
-  const float* x1;
-  long long ldx1;
-  const int* rows;
-  int n;
-  const float* w1;
-  long long ldw1;
-  const float* b1;
-  const float* w2;
-  long long ldw2;
-  const float* b2;
-  const float* mask;
-  long long ldmask;
-  float* hid_out;
-  long long ldhid;
-  float* out;
-  long long ldout;
-  int add_act;   // 1: out = act(out_old + acc + b2), 0: out = acc + b2
-  int relu_out;
-};
-
-// Weight panels are read from L2 ONCE per workgroup, at kernel entry, with every 16-byte load of both layers in
-// flight together (64 per thread = 256 VGPRs; the kernel runs one workgroup per CU, so the 512-entry register file
-// has room).  The K loops then only move registers -> LDS -> MFMA fragments: no global round trip sits on the
-// serial path of a level (the two-launch form paid one L2 round trip per 16-deep K step).
-template <bool KM, int N, int KT>   // tile kt of a weight with N output features; KT = number of 32-deep tiles
-struct WPanel {
-  static constexpr int PER = N * M2_BK / 4 / 256;
-  f32x4 r[KT][PER];
-  __device__ __forceinline__ void load(const float* w, long long ldw, int tid) {
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        int g = tid + i * 256;
-        if (KM) {
-          int kk = g / (N / 4), n4 = g % (N / 4);
-          r[kt][i] = *reinterpret_cast<const f32x4*>(w + (long long)(kt * M2_BK + kk) * ldw + n4 * 4);
-        } else {
-          int rr = g / (M2_BK / 4), k4 = g % (M2_BK / 4);
-          r[kt][i] = *reinterpret_cast<const f32x4*>(w + (long long)rr * ldw + kt * M2_BK + k4 * 4);
-        }
-      }
-  }
-  template <int KTI>
-  __device__ __forceinline__ void to_lds(float* dst, int tid) const {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      int g = tid + i * 256;
-      if (KM) {
-        int kk = g / (N / 4), n4 = g % (N / 4);
-        *reinterpret_cast<f32x4*>(dst + kk * (N + 4) + n4 * 4) = r[KTI][i];
-      } else {
-        int rr = g / (M2_BK / 4), k4 = g % (M2_BK / 4);
-        *reinterpret_cast<f32x4*>(dst + rr * (M2_BK + 8) + k4 * 4) = r[KTI][i];
-      }
-    }
-  }
-};
-
-template <bool KM, int KTI, int NK>
-struct Phase1 {
-  template <class P>
-  static __device__ __forceinline__ void run(const P& pan, const float* xs, float* wb, int wsz, int tid, int lane, int wave,
-                                             f32x4 (&acc)[2][4]) {
-    constexpr int XS = M2_K1 + 8;
-    constexpr int WS = KM ? (M2_HD + 4) : (M2_BK + 8);
-    float* wt = wb + (KTI & 1) * wsz;
-    pan.template to_lds<KTI>(wt, tid);
-    __syncthreads();
-#pragma unroll
-    for (int kb = 0; kb < M2_BK / 16; ++kb) {
-      float xf[2][4], wf[4][4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) read_frag<false, XS>(xs, i * 16, KTI * (M2_BK / 16) + kb, lane, xf[i]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) read_frag<KM, WS>(wt, wave * 64 + j * 16, kb, lane, wf[j]);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][s], xf[i][s], acc[i][j], 0, 0, 0);
-    }
-    if constexpr (KTI + 1 < NK) Phase1<KM, KTI + 1, NK>::run(pan, xs, wb, wsz, tid, lane, wave, acc);
-  }
-};
-
-template <bool KM, int KTI, int NK>
-struct Phase2 {
-  template <class P>
-  static __device__ __forceinline__ void run(const P& pan, const float* hs, float* wb, int wsz, int tid, int lane, int wave,
-                                             f32x4 (&acc)[2][2]) {
-    constexpr int HS = M2_HD + 8;
-    constexpr int WS = KM ? (M2_D2 + 4) : (M2_BK + 8);
-    float* wt = wb + (KTI & 1) * wsz;
-    pan.template to_lds<KTI>(wt, tid);
-    __syncthreads();
-#pragma unroll
-    for (int kb = 0; kb < M2_BK / 16; ++kb) {
-      float xf[2][4], wf[2][4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) read_frag<false, HS>(hs, i * 16, KTI * (M2_BK / 16) + kb, lane, xf[i]);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) read_frag<KM, WS>(wt, wave * 32 + j * 16, kb, lane, wf[j]);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][s], xf[i][s], acc[i][j], 0, 0, 0);
-    }
-    if constexpr (KTI + 1 < NK) Phase2<KM, KTI + 1, NK>::run(pan, hs, wb, wsz, tid, lane, wave, acc);
-  }
-};
 
 template <bool KM>
 __global__ void __launch_bounds__(256, 1) mlp2_rows_kernel(Mlp2Args a) {

@@ -30,6 +30,8 @@ def header_decls():
                 prm = prm.strip()
                 if '*' in prm:
                     args.append(ctypes.c_void_p)
+                elif prm.startswith('unsigned'):
+                    args.append(ctypes.c_uint)
                 elif prm.startswith('long long'):
                     args.append(ctypes.c_longlong)
                 elif prm.startswith('int'):

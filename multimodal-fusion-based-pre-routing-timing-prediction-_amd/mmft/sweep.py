@@ -247,6 +247,38 @@ def level_forward(conv, graph, cur_nodes, targets, level_id):
 #   * backward = scatter of all target gradients, the reverse pull sweep, batched weight gradients.
 # Same arithmetic as the per-level path (same kernels, same per-row operation order).
 # ------------------------------------------------------------------------------------------------
+# Experimental: one persistent launch (in-kernel grid barriers, weights resident in registers) for the forward level
+# chain.  Correct (tests/test_model_gpu.py::test_persistent_forward_sweep) but SLOWER than per-level launches on
+# MI355X at config B (3.1 ms vs 1.9 ms per forward sweep, tools/bench_sweep.py): a 32-row tile costs ~20 us at one
+# wave per SIMD either way, and the software barrier over 252 workgroups (arrival skew of the slowest tile included)
+# costs more than the ~2 us hardware kernel boundary it replaces.  Off by default.
+PERSISTENT_FORWARD = False
+
+
+def _persist_state(graph, level_rows):
+    """Level table + barrier words for mmft_sweep_fwd_persistent, cached on the graph (the level lists are static)."""
+    key = tuple(int(r.data_ptr()) for r in level_rows) + tuple(int(r.numel()) for r in level_rows)
+    ps = graph.__dict__.get('_persist')
+    if ps is None or ps['key'] != key:
+        dev = graph.device
+        counts = [int(r.numel()) for r in level_rows]
+        ptr = torch.tensor([0] + list(torch.tensor(counts).cumsum(0).tolist()), dtype=torch.int32, device=dev)
+        rows = torch.cat([r for r in level_rows]) if sum(counts) else torch.zeros(1, dtype=torch.int32, device=dev)
+        ps = dict(key=key, ptr=ptr, rows=rows.contiguous(), max_rows=max(counts[1:]) if len(counts) > 1 else 0,
+                  counter=torch.zeros(1, dtype=torch.int32, device=dev), err=torch.zeros(1, dtype=torch.int32, device=dev),
+                  err_host=torch.zeros(1, dtype=torch.int32).pin_memory())
+        graph.__dict__['_persist'] = ps
+    return ps
+
+
+def check_persistent_error(graph):
+    """Raise if a previous persistent sweep reported a barrier time-out (host read of a pinned word, no sync)."""
+    ps = graph.__dict__.get('_persist')
+    if ps is not None and int(ps['err_host'][0]) != 0:
+        raise RuntimeError('persistent sweep kernel: a grid-barrier wait ran out (workgroups not co-resident?); '
+                           'results of that step are invalid - set mmft.sweep.PERSISTENT_FORWARD = False')
+
+
 class SweepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, state, level_rows, tix, *params):
@@ -269,8 +301,15 @@ class SweepFn(torch.autograd.Function):
             ops.linear_fwd(st.net_feat, w1n, b1n, y=st.HS, xidx=rn, yidx=rn, act=ops.ACT_RELU)
             ops.linear_fwd(st.HS, w2n, b2n, y=st.h, xidx=rn, yidx=rn)
         in_net, in_cell = g.csr('in', 'net'), g.csr('in', 'cell')
+        persistent = PERSISTENT_FORWARD and ops.mlp2_fusable(st.D, st.Hd, st.D) and len(level_rows) > 1
+        if persistent:
+            check_persistent_error(g)
+            ps = _persist_state(g, level_rows)
+            ops.sweep_fwd_persistent(st.h, st.A, st.LSE, st.HN, in_net, in_cell, ps['ptr'], ps['rows'], len(level_rows),
+                                     w1g, b1g, w2g, b2g, st.relu, ps['max_rows'], ps['counter'], ps['err'])
+            ps['err_host'].copy_(ps['err'], non_blocking=True)
         for level_id, rows in enumerate(level_rows):
-            if level_id == 0 or not rows.numel():
+            if persistent or level_id == 0 or not rows.numel():
                 continue
             if level_id % 2 == 1:
                 ops.seg_mean_add_act_fwd(st.h, in_net, rows, relu=st.relu)

@@ -70,7 +70,7 @@ def test_empty_levels_and_levels_without_targets(dev):
         g.ndata['h'] = torch.zeros((d.N, 128), device=dev)
         assert pmodel.forward_sweep(g, [l.tolist() for l in d.levels], torch.zeros(0, dtype=torch.int32, device=dev),
                                     torch.zeros(0, dtype=torch.int32, device=dev), None) is None
-        assert torch.equal(h_a, g.ndata['h'])
+        assert rel_err(g.ndata['h'], h_a) < 1e-6          # other kernels (persistent sweep): same math, not bitwise
 
 
 def test_sweep_order_is_enforced(dev):
