@@ -148,12 +148,14 @@ class TrainStep:
                 else:
                     h_gnn = _sweep.sweep_forward_all(self.pmodel.gnn, g, b.level_nodes, ends_d)
             feat = self.cnn(b.images).reshape(b.B, -1) if self.cnn is not None else None
+            pm = MaskedPathMap(b.masks, paths_d, feat, foff_d if b.B > 1 else None, *b.links) \
+                if feat is not None else None
+            # the masked projection needs only the CNN output: issue it before joining the sweep stream
+            h_cnn = self.pmodel._fcn(pm) if (pm is not None and self.pmodel.fcn is not None) else None
             if h_gnn is not None and self.overlap:
                 cur.wait_stream(self.side)
                 h_gnn.record_stream(cur)
-            pm = MaskedPathMap(b.masks, paths_d, feat, foff_d if b.B > 1 else None, *b.links) \
-                if feat is not None else None
-            return self.pmodel.fuse_heads(h_gnn, pm, lv_d, b.L), ends_d, ends_h
+            return self.pmodel.fuse_heads(h_gnn, pm, lv_d, b.L, h_cnn=h_cnn), ends_d, ends_h
         feat = self.cnn(b.images).reshape(b.B, -1) if self.cnn is not None else None      # src/train.py:465,562
         hats, pos = [], 0
         for level_id in range(b.L):                                                       # src/train.py:490-511

@@ -181,10 +181,12 @@ class PathModel(nn.Module):
         h_gnn = _sweep.sweep_forward_all(self.gnn, graph, level_nodes, targets) if self.gnn is not None else None
         return self.fuse_heads(h_gnn, path_map, target_levels, len(level_nodes))
 
-    def fuse_heads(self, h_gnn, path_map, target_levels, num_levels):
+    def fuse_heads(self, h_gnn, path_map, target_levels, num_levels, h_cnn=None):
         """Fusion head over all T endpoints at once: fcn(path_map), mlp_alpha(level of each endpoint), mlp_fuse
-        (src/model.py:271-292 with the level-invariant work hoisted)."""
-        h_cnn = self._fcn(path_map) if (self.fcn is not None and path_map is not None) else None
+        (src/model.py:271-292 with the level-invariant work hoisted).  `h_cnn` may be passed pre-computed
+        (= self._fcn(path_map)) so that the caller can overlap it with the tail of the sweep."""
+        if h_cnn is None:
+            h_cnn = self._fcn(path_map) if (self.fcn is not None and path_map is not None) else None
         lv = th.arange(num_levels, dtype=th.float32, device=target_levels.device).unsqueeze(1)
         h_global = MF.gather_rows(self.mlp_alpha(lv), target_levels)          # (T, 32), row = alpha(level of t)
         parts = [p for p in (h_gnn, h_cnn, h_global) if p is not None]
