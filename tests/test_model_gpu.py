@@ -453,3 +453,77 @@ def test_persistent_forward_sweep(dev):
     close(res[True][1], res[False][1], 1e-6, 'h')
     close(res[True][0], res[False][0], 1e-6, 'hats')
     close(res[True][2], res[False][2], 1e-5, 'grads')
+
+
+def test_reference_style_training_loop(dev):
+    """The reference's own loop shape (src/train.py:431-443,461-562) run verbatim against the drop-in modules:
+    torch.optim.Adam over chain(model, cnn), nn.MSELoss, DataLoader(PathDataset) batches, dense
+    `path_mask.to_dense()*feat_map`, per-level model(...) calls, loss.backward(retain_graph=True), fresh zero
+    ndata['h'] and a re-run of the CNN after every step.  Three steps vs the fp64 oracle on the same batches."""
+    import itertools
+    import model as M
+    from MyDataloader import PathDataset
+    from torch.utils.data import DataLoader
+    from mmft.synth import synth_design
+    from mmft.train import build_models
+    d = synth_design(N=2048, L=10, tile=32, seed=61, end_frac=0.5)
+    pmodel, cnn = build_models(map_size=d.map_size, device=dev, seed=9294)
+    oracle = R.OracleTrainer({k: v.detach().cpu().clone() for k, v in pmodel.state_dict().items()},
+                             {k: v.detach().cpu().clone() for k, v in cnn.state_dict().items()}, dtype=torch.float64)
+    csr = R.design_csr(d)
+    graph = PinGraph.from_synth(d).to(dev)
+    topo_levels = d.topo_levels()
+    path2level = {p: int(l) for p, l in enumerate(d.path2level)}
+    path2endpoint = {p: int(e) for p, e in enumerate(d.path2endpoint)}
+    rows = np.repeat(np.arange(d.num_paths), np.diff(d.mask_indptr))
+    path_masks = torch.sparse_coo_tensor(np.stack([rows, d.mask_cols]), torch.ones(rows.shape[0], dtype=torch.int64),
+                                         (d.num_paths, d.map_size ** 2)).coalesce()
+    cnn_inputs = torch.from_numpy(d.image)
+    Loss = torch.nn.MSELoss()
+    optim = torch.optim.Adam(itertools.chain(pmodel.parameters(), cnn.parameters()), 1e-3, weight_decay=0)
+    cnn.train(); pmodel.train()
+    torch.manual_seed(0)
+    loader = DataLoader(PathDataset(list(range(d.num_paths))), batch_size=48, shuffle=True, drop_last=True)
+    graph.ndata['h'] = torch.zeros((graph.number_of_nodes(), 128), dtype=torch.float).to(dev)
+    feat_map = cnn(cnn_inputs.to(dev)).reshape((1, -1))
+    losses, losses_o = [], []
+    for bidx, path_ids in enumerate(loader):
+        if bidx == 3:
+            break
+        path_ids = list(path_ids.numpy().tolist())
+        sampled_ends, sampled_paths = {}, {}
+        for pathid in path_ids:
+            level, endpoint = path2level[pathid], path2endpoint[pathid]
+            sampled_ends.setdefault(level, []).append(endpoint)
+            sampled_paths.setdefault(level, []).append(pathid)
+        label_hats, target_list = None, []
+        for level_id, level in enumerate(topo_levels):
+            nodes, eids = level[:2]
+            targets, paths = sampled_ends.get(level_id, []), sampled_paths.get(level_id, [])
+            target_list.extend(targets)
+            if len(paths) == 0:
+                path_map = None
+            else:
+                path_mask = torch.index_select(path_masks, 0, torch.tensor(paths)).to(dev)
+                path_map = path_mask.to_dense() * feat_map
+            cur = pmodel(graph, nodes, eids, targets, level_id,
+                         torch.tensor(level_id, dtype=torch.float).unsqueeze(0).to(dev), path_map)
+            if len(paths) == 0:
+                continue
+            label_hats = cur if label_hats is None else torch.cat((label_hats, cur), dim=0)
+        arrival_time = graph.ndata['arrival_time'][target_list].squeeze()
+        train_loss = Loss(label_hats, arrival_time)
+        optim.zero_grad()
+        train_loss.backward(retain_graph=True)
+        optim.step()
+        losses.append(float(train_loss.detach()))
+        graph.ndata['h'] = torch.zeros((graph.number_of_nodes(), 128), dtype=torch.float).to(dev)
+        feat_map = cnn(cnn_inputs.to(dev)).reshape((1, -1))
+        lo, _, tl_o = oracle.step(d, csr, path_ids)      # its CNN forward = the feat_map computed before this step
+        assert tl_o == target_list
+        losses_o.append(lo)
+    R.unet_forward(oracle.pc, torch.from_numpy(d.image).double())    # the loop's trailing cnn(...) call
+    np.testing.assert_allclose(losses, losses_o, rtol=2e-3)
+    sd = cnn.state_dict()
+    close(sd['inc.double_conv.1.running_var'], oracle.pc['inc.double_conv.1.running_var'], 1e-3, 'running_var')
+    assert int(sd['inc.double_conv.1.num_batches_tracked']) == int(oracle.pc['inc.double_conv.1.num_batches_tracked'])
