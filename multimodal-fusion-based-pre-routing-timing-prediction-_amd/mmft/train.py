@@ -48,24 +48,46 @@ def trainable_parameters(pmodel, cnn):
 class DesignBatch:
     """B designs resident on the device, merged block-diagonally."""
 
-    def __init__(self, designs, device, out_dim=128):
+    def __init__(self, designs, device, out_dim=128, renumber=True):
+        """renumber: give the merged nodes level-major ids (level 0 of every design first, then level 1, ...), so that
+        every level is one contiguous id range: the level's own rows of h / G / A stream through memory and the
+        gathered neighbour rows of adjacent levels sit next to each other.  Purely internal: ids handed back to the
+        caller are the original merged ids."""
         self.designs = designs
         self.B = len(designs)
         self.device = torch.device(device)
-        graphs = [PinGraph.from_synth(d) for d in designs]
-        g = graphs[0] if self.B == 1 else PinGraph.batch(graphs)
-        self.graph = g.to(device)
-        self.N = self.graph.number_of_nodes()
-        self.out_dim = out_dim
-        self.L = max(d.L for d in designs)
         self.node_off = np.concatenate([[0], np.cumsum([d.N for d in designs])]).astype(np.int64)
         self.path_off = np.concatenate([[0], np.cumsum([d.num_paths for d in designs])]).astype(np.int64)
-        self.P = designs[0].map_size ** 2
-        # same-index levels concatenated; python int lists, as the reference passes them (src/dataset.py:124-129)
-        self.level_nodes = []
+        self.N = int(self.node_off[-1])
+        self.L = max(d.L for d in designs)
+        levels_old = []
         for l in range(self.L):
             parts = [d.levels[l] + self.node_off[i] for i, d in enumerate(designs) if l < d.L]
-            self.level_nodes.append(np.concatenate(parts).tolist())
+            levels_old.append(np.concatenate(parts))
+        if renumber:
+            order = np.concatenate(levels_old)                       # new id k <- old id order[k]
+            rest = np.setdiff1d(np.arange(self.N), order)             # nodes in no level keep trailing ids
+            order = np.concatenate([order, rest])
+            new_of_old = np.empty(self.N, dtype=np.int64)
+            new_of_old[order] = np.arange(self.N)
+        else:
+            order = new_of_old = np.arange(self.N)
+        self.old_of_new = order
+        cat = lambda key: np.concatenate([getattr(d, key) + self.node_off[i] for i, d in enumerate(designs)])
+        g = PinGraph(self.N, {'net': (new_of_old[cat('net_src')], new_of_old[cat('net_dst')]),
+                              'cell': (new_of_old[cat('cell_src')], new_of_old[cat('cell_dst')])})
+        rows = lambda key: torch.from_numpy(np.concatenate([getattr(d, key) for d in designs])[order])
+        g.ndata['cell_feat'] = rows('cell_feat')
+        g.ndata['net_feat'] = rows('net_feat')
+        g.ndata['arrival_time'] = rows('arrival_time')
+        g.ndata['required_time'] = rows('required_time')
+        g.ndata['label'] = rows('label')
+        g.ndata['end'] = rows('is_end')
+        self.graph = g.to(device)
+        self.out_dim = out_dim
+        self.P = designs[0].map_size ** 2
+        # same-index levels concatenated; python int lists, as the reference passes them (src/dataset.py:124-129)
+        self.level_nodes = [new_of_old[lv].tolist() for lv in levels_old]
         masks = [PathMasks(d.mask_indptr, d.mask_cols, d.map_size ** 2, device) for d in designs]
         self.masks = masks[0] if self.B == 1 else PathMasks.batch(masks)
         self.images = torch.from_numpy(np.stack([d.image for d in designs])).to(device)
@@ -73,7 +95,7 @@ class DesignBatch:
         self.required = self.graph.ndata['required_time']
         self.level_th = [torch.tensor([float(l)], device=device) for l in range(self.L)]
         self.path2level = np.concatenate([d.path2level for d in designs])
-        self.path2endpoint = np.concatenate([d.path2endpoint + self.node_off[i] for i, d in enumerate(designs)])
+        self.path2endpoint = new_of_old[np.concatenate([d.path2endpoint + self.node_off[i] for i, d in enumerate(designs)])]
         self.path2design = np.concatenate([np.full(d.num_paths, i, dtype=np.int64) for i, d in enumerate(designs)])
 
     def select(self, path_ids_per_design, static=None):
@@ -97,7 +119,7 @@ class DesignBatch:
         else:
             dev = torch.from_numpy(packed).to(self.device)
         self.links = (dev[5 * T:], dev[4 * T:5 * T])
-        return dev[0:T], dev[T:2 * T], dev[2 * T:3 * T], counts, ends, dev[3 * T:4 * T]
+        return dev[0:T], dev[T:2 * T], dev[2 * T:3 * T], counts, self.old_of_new[ends], dev[3 * T:4 * T]
 
 
 class TrainStep:

@@ -120,7 +120,7 @@ def test_batch_links_and_transposed_masks():
 def test_design_batch_select_order():
     from mmft.train import DesignBatch
     ds = [synth_design(N=512, L=8, tile=16, seed=10 + i, end_frac=0.5) for i in range(2)]
-    b = DesignBatch(ds, 'cpu')
+    b = DesignBatch(ds, 'cpu', renumber=False)
     ids = [[5, 0, 7, 0], [1, 3]]
     ends, paths, foff, counts, ends_h, lv = b.select(ids)
     # ordered by level, then design, then appearance (src/train.py:476-484 for B = 1)
@@ -131,6 +131,17 @@ def test_design_batch_select_order():
     assert counts.sum() == 6 and len(b.level_nodes) == 8
     first, nxt = b.links
     assert first.numel() == b.path_off[-1] and nxt.numel() == 6
+    # level-major renumbering is internal: every level becomes one contiguous id range, ids handed back are unchanged
+    r = DesignBatch(ds, 'cpu', renumber=True)
+    ends_r, _, _, _, ends_h_r, _ = r.select(ids)
+    assert ends_h_r.tolist() == ends_h.tolist() and r.old_of_new[ends_r.numpy()].tolist() == ends_h.tolist()
+    start = 0
+    for lv_nodes in r.level_nodes:
+        assert lv_nodes == list(range(start, start + len(lv_nodes)))
+        start += len(lv_nodes)
+    assert torch.equal(r.graph.ndata['cell_feat'], b.graph.ndata['cell_feat'][torch.from_numpy(r.old_of_new)])
+    src, dst = r.graph._coo['net']
+    assert sorted(zip(r.old_of_new[src].tolist(), r.old_of_new[dst].tolist())) == sorted(zip(*[a.tolist() for a in b.graph._coo['net']]))
 
 
 def test_design_record_roundtrip_and_reference_tuple_converter(tmp_path):
