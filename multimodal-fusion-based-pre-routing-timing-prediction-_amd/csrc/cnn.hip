@@ -571,8 +571,7 @@ int mmft_pool2x2_fwd(const float* x, float* y, int Nimg, int H, int W, int C, in
   MMFT_REQUIRE(x && y && Nimg > 0 && H >= 2 && W >= 2 && C > 0 && (mode == 0 || mode == 1), "pool2x2_fwd: bad args");
   DeviceGuard dg(device);
   long long total = (long long)Nimg * (H / 2) * (W / 2) * C;
-  ProfScope ps("pool_fwd_kernel", 0.0, 5.0 * total, (hipStream_t)stream);
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, Nimg, H, W, C, mode);
+  MMFT_LAUNCH("pool_fwd_kernel", 0.0, 5.0 * total, pool_fwd_kernel, dim3(ew_grid(total)), dim3(256), (hipStream_t)stream, x, y, Nimg, H, W, C, mode);
   return check_launch("pool2x2_fwd");
 }
 
@@ -581,8 +580,7 @@ int mmft_pool2x2_bwd(const float* x, const float* gy, float* dx, int Nimg, int H
   MMFT_REQUIRE(x && gy && dx && Nimg > 0 && H >= 2 && W >= 2 && C > 0 && (mode == 0 || mode == 1), "pool2x2_bwd: bad args");
   DeviceGuard dg(device);
   long long total = (long long)Nimg * H * W * C;
-  ProfScope ps("pool_bwd_kernel", 0.0, 9.0 * total, (hipStream_t)stream);
-  hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, gy, dx, Nimg, H, W, C, mode);
+  MMFT_LAUNCH("pool_bwd_kernel", 0.0, 9.0 * total, pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), (hipStream_t)stream, x, gy, dx, Nimg, H, W, C, mode);
   return check_launch("pool2x2_bwd");
 }
 
@@ -591,9 +589,7 @@ int mmft_pixel_shuffle2(const float* in, const float* bias, float* out, int Nimg
   MMFT_REQUIRE(in && out && Nimg > 0 && H > 0 && W > 0 && Co > 0, "pixel_shuffle2: bad args");
   DeviceGuard dg(device);
   long long total = (long long)Nimg * H * W * 4 * Co;
-  ProfScope ps("pixel_shuffle_kernel", 0.0, 8.0 * total, (hipStream_t)stream);
-  hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, in, bias, out, Nimg, H,
-                     W, Co, 0);
+  MMFT_LAUNCH("pixel_shuffle_kernel", 0.0, 8.0 * total, pixel_shuffle_kernel, dim3(ew_grid(total)), dim3(256), (hipStream_t)stream, in, bias, out, Nimg, H, W, Co, 0);
   return check_launch("pixel_shuffle2");
 }
 
@@ -601,9 +597,7 @@ int mmft_pixel_unshuffle2(const float* in, float* out, int Nimg, int H, int W, i
   MMFT_REQUIRE(in && out && Nimg > 0 && H > 0 && W > 0 && Co > 0, "pixel_unshuffle2: bad args");
   DeviceGuard dg(device);
   long long total = (long long)Nimg * H * W * 4 * Co;
-  ProfScope ps("pixel_shuffle_kernel", 0.0, 8.0 * total, (hipStream_t)stream);
-  hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, in, nullptr, out, Nimg,
-                     H, W, Co, 1);
+  MMFT_LAUNCH("pixel_shuffle_kernel", 0.0, 8.0 * total, pixel_shuffle_kernel, dim3(ew_grid(total)), dim3(256), (hipStream_t)stream, in, nullptr, out, Nimg, H, W, Co, 1);
   return check_launch("pixel_unshuffle2");
 }
 
@@ -614,9 +608,7 @@ int mmft_copy_region_nhwc(float* src, int Nimg, int Hs, int Ws, int Cs, float* d
                "copy_region_nhwc: region outside destination");
   DeviceGuard dg(device);
   long long total = (long long)Nimg * Hs * Ws * Cs;
-  ProfScope ps("copy_region_kernel", 0.0, 8.0 * total, (hipStream_t)stream);
-  hipLaunchKernelGGL(copy_region_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, src, Nimg, Hs, Ws, Cs,
-                     dst, Hd, Wd, Cd, c_off, y_off, x_off, reverse);
+  MMFT_LAUNCH("copy_region_kernel", 0.0, 8.0 * total, copy_region_kernel, dim3(ew_grid(total)), dim3(256), (hipStream_t)stream, src, Nimg, Hs, Ws, Cs, dst, Hd, Wd, Cd, c_off, y_off, x_off, reverse);
   return check_launch("copy_region_nhwc");
 }
 

@@ -1,6 +1,7 @@
 // Shared helpers for libmmft_hip.so (gfx950 / CDNA4 only; wave64).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -56,6 +57,23 @@ struct ProfScope {
     if (on) prof_end(st);
   }
 };
+
+// Single-kernel launch sites use hipExtLaunchKernelGGL while profiling: its start/stop events carry the kernel's own
+// begin/end timestamps (what rocprofv3 reports), not the stream position of an event recorded from the host, so
+// 8-20 us kernels are not inflated by launch gaps.
+void prof_events(const char* name, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1);
+void prof_commit();
+#define MMFT_LAUNCH(name, flops, bytes, kernel, grid, block, st, ...)                                        \
+  do {                                                                                                       \
+    if (mmft::prof_on()) {                                                                                   \
+      hipEvent_t mmft_e0_, mmft_e1_;                                                                         \
+      mmft::prof_events(name, flops, bytes, &mmft_e0_, &mmft_e1_);                                           \
+      hipExtLaunchKernelGGL(kernel, grid, block, 0, st, mmft_e0_, mmft_e1_, 0, __VA_ARGS__);                 \
+      mmft::prof_commit();                                                                                   \
+    } else {                                                                                                 \
+      hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                                           \
+    }                                                                                                        \
+  } while (0)
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

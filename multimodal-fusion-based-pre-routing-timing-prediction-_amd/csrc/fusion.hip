@@ -221,9 +221,7 @@ int mmft_masked_fc_fwd(const int* mask_indptr, const int* mask_cols, const int* 
   MMFT_REQUIRE(aligned16(wT) && aligned16(out) && (!bias || aligned16(bias)), "masked_fc_fwd: 16-byte alignment");
   if (T == 0) return MMFT_OK;
   DeviceGuard dg(device);
-  ProfScope ps("masked_fc_fwd_kernel", 0.0, 0.0, (hipStream_t)stream);
-  hipLaunchKernelGGL(masked_fc_fwd_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream,
-                     mask_indptr, mask_cols, paths, f_off, T, f, wT, bias, out, Dout);
+  MMFT_LAUNCH("masked_fc_fwd_kernel", 0.0, 0.0, masked_fc_fwd_kernel, dim3(T), dim3(256), (hipStream_t)stream, mask_indptr, mask_cols, paths, f_off, T, f, wT, bias, out, Dout);
   return check_launch("masked_fc_fwd");
 }
 
@@ -238,18 +236,14 @@ int mmft_masked_fc_bwd(const int* csc_indptr, const int* csc_paths, const int* f
   int groups = Dout / 4, cpb = 256 / groups;
   hipStream_t st = (hipStream_t)stream;
   if (B == 1) {
-    ProfScope ps("masked_fc_bwd_kernel", 0.0, 0.0, st);
-    hipLaunchKernelGGL(masked_fc_bwd_kernel, dim3(cdiv(P, cpb), 1), dim3(256), 0, st, csc_indptr, csc_paths, first, next,
-                       gout, f, wT, dwT, df, B, P, Dout);
+    MMFT_LAUNCH("masked_fc_bwd_kernel", 0.0, 0.0, masked_fc_bwd_kernel, dim3(cdiv(P, cpb), 1), dim3(256), st, csc_indptr, csc_paths, first, next, gout, f, wT, dwT, df, B, P, Dout);
     return check_launch("masked_fc_bwd");
   }
   // one block column per design: B-fold parallelism; the per-design dwT slabs are summed in fixed order
   long long need = (long long)B * P * Dout * 4;
   MMFT_REQUIRE(workspace && workspace_bytes >= need && aligned16(workspace), "masked_fc_bwd: workspace too small");
   {
-    ProfScope ps("masked_fc_bwd_kernel", 0.0, 0.0, st);
-    hipLaunchKernelGGL(masked_fc_bwd_kernel, dim3(cdiv(P, cpb), B), dim3(256), 0, st, csc_indptr, csc_paths, first, next,
-                       gout, f, wT, workspace, df, B, P, Dout);
+    MMFT_LAUNCH("masked_fc_bwd_kernel", 0.0, 0.0, masked_fc_bwd_kernel, dim3(cdiv(P, cpb), B), dim3(256), st, csc_indptr, csc_paths, first, next, gout, f, wT, workspace, df, B, P, Dout);
   }
   int rc = check_launch("masked_fc_bwd");
   if (rc) return rc;
@@ -278,9 +272,7 @@ int mmft_adam_step(float* p, const float* g, float* m, float* v, long long n, fl
   MMFT_REQUIRE(bias_correction1 > 0.f && bias_correction2 > 0.f, "adam_step: bias corrections must be positive");
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
-  ProfScope ps("adam_kernel", 0.0, 28.0 * n, (hipStream_t)stream);
-  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr / bias_correction1,
-                     beta1, beta2, eps, weight_decay, sqrtf(bias_correction2), gscale, (const float*)nullptr);
+  MMFT_LAUNCH("adam_kernel", 0.0, 28.0 * n, adam_kernel, dim3(ew_grid(n)), dim3(256), (hipStream_t)stream, p, g, m, v, n, lr / bias_correction1, beta1, beta2, eps, weight_decay, sqrtf(bias_correction2), gscale, (const float*)nullptr);
   return check_launch("adam_step");
 }
 
@@ -289,9 +281,7 @@ int mmft_adam_step_dev(float* p, const float* g, float* m, float* v, long long n
   MMFT_REQUIRE(p && g && m && v && step_scalars && n >= 0, "adam_step_dev: bad args");
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
-  ProfScope ps("adam_kernel", 0.0, 28.0 * n, (hipStream_t)stream);
-  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, 0.f, beta1, beta2, eps,
-                     weight_decay, 1.f, gscale, step_scalars);
+  MMFT_LAUNCH("adam_kernel", 0.0, 28.0 * n, adam_kernel, dim3(ew_grid(n)), dim3(256), (hipStream_t)stream, p, g, m, v, n, 0.f, beta1, beta2, eps, weight_decay, 1.f, gscale, step_scalars);
   return check_launch("adam_step_dev");
 }
 

@@ -476,8 +476,7 @@ inline void launch_cfg(const XL& xl, const WL& wl, const Epi& epi, int M, int N,
   }
   dim3 grid(cdiv(M, CFG::BM), cdiv(N, CFG::BN), splits);
   // algorithmic work of this launch: 2*M*N*K flops; bytes = the three matrices touched once
-  ProfScope ps(gemm_kernel_name<CFG, XL, WL>(), 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), st);
-  hipLaunchKernelGGL((gemm_f32_kernel<CFG, XL, WL>), grid, dim3(256), 0, st, xl, wl, epi, M, N, K, ksplit);
+  MMFT_LAUNCH((gemm_kernel_name<CFG, XL, WL>()), 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), (gemm_f32_kernel<CFG, XL, WL>), grid, dim3(256), st, xl, wl, epi, M, N, K, ksplit);
 }
 
 // number of split-K slabs launch_gemm will actually use for a requested count

@@ -179,9 +179,7 @@ int mmft_seg_softmax_sum_fwd(const float* h, long long ldh, const int* in_indptr
                "seg_softmax_sum_fwd: rows must be 16-byte aligned");
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
-  ProfScope ps("seg_softmax_sum_fwd_kernel", 0.0, 3.0 * 4.0 * n * D, (hipStream_t)stream);
-  hipLaunchKernelGGL(seg_softmax_sum_fwd_kernel, dim3(node_grid(n, D)), dim3(256), 0, (hipStream_t)stream, h, ldh,
-                     in_indptr, in_indices, rows, n, D, A, LSE, lda);
+  MMFT_LAUNCH("seg_softmax_sum_fwd_kernel", 0.0, 3.0 * 4.0 * n * D, seg_softmax_sum_fwd_kernel, dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, h, ldh, in_indptr, in_indices, rows, n, D, A, LSE, lda);
   return check_launch("seg_softmax_sum_fwd");
 }
 
@@ -192,9 +190,7 @@ int mmft_seg_mean_add_act_fwd(float* h, long long ldh, const int* in_indptr, con
   MMFT_REQUIRE(ldh >= D && ldh % 4 == 0 && aligned16(h), "seg_mean_add_act_fwd: rows must be 16-byte aligned");
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
-  ProfScope ps("seg_mean_fwd_kernel", 0.0, 3.0 * 4.0 * n * D, (hipStream_t)stream);
-  hipLaunchKernelGGL(seg_mean_fwd_kernel, dim3(node_grid(n, D)), dim3(256), 0, (hipStream_t)stream, h, ldh, in_indptr,
-                     in_indices, rows, n, D, h, ldh, 1, relu, 1);
+  MMFT_LAUNCH("seg_mean_fwd_kernel", 0.0, 3.0 * 4.0 * n * D, seg_mean_fwd_kernel, dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, h, ldh, in_indptr, in_indices, rows, n, D, h, ldh, 1, relu, 1);
   return check_launch("seg_mean_add_act_fwd");
 }
 
@@ -206,9 +202,7 @@ int mmft_seg_mean_fwd(const float* src, long long lds, const int* in_indptr, con
                "seg_mean_fwd: rows must be 16-byte aligned");
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
-  ProfScope ps("seg_mean_fwd_kernel", 0.0, 3.0 * 4.0 * n * D, (hipStream_t)stream);
-  hipLaunchKernelGGL(seg_mean_fwd_kernel, dim3(node_grid(n, D)), dim3(256), 0, (hipStream_t)stream, src, lds,
-                     in_indptr, in_indices, rows, n, D, out, ldo, 0, 0, 1);
+  MMFT_LAUNCH("seg_mean_fwd_kernel", 0.0, 3.0 * 4.0 * n * D, seg_mean_fwd_kernel, dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, src, lds, in_indptr, in_indices, rows, n, D, out, ldo, 0, 0, 1);
   return check_launch("seg_mean_fwd");
 }
 
@@ -220,9 +214,7 @@ int mmft_seg_sum_fwd(const float* src, long long lds, const int* indptr, const i
                "seg_sum_fwd: rows must be 16-byte aligned");
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
-  ProfScope ps("seg_mean_fwd_kernel", 0.0, 3.0 * 4.0 * n * D, (hipStream_t)stream);
-  hipLaunchKernelGGL(seg_mean_fwd_kernel, dim3(node_grid(n, D)), dim3(256), 0, (hipStream_t)stream, src, lds, indptr,
-                     indices, rows, n, D, out, ldo, accumulate ? 1 : 0, 0, 0);
+  MMFT_LAUNCH("seg_mean_fwd_kernel", 0.0, 3.0 * 4.0 * n * D, seg_mean_fwd_kernel, dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, src, lds, indptr, indices, rows, n, D, out, ldo, accumulate ? 1 : 0, 0, 0);
   return check_launch("seg_sum_fwd");
 }
 
@@ -238,10 +230,7 @@ int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows,
                "level_bwd_pull: rows must be 16-byte aligned");
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
-  ProfScope ps("level_bwd_pull_kernel", 0.0, 3.0 * 4.0 * n * D, (hipStream_t)stream);
-  hipLaunchKernelGGL(level_bwd_pull_kernel, dim3(node_grid(n, D)), dim3(256), 0, (hipStream_t)stream, G, h, ld, rows,
-                     n, D, out_net_indptr, out_net_indices, out_net_weight, out_cell_indptr, out_cell_indices, A, LSE,
-                     DA, relu);
+  MMFT_LAUNCH("level_bwd_pull_kernel", 0.0, 3.0 * 4.0 * n * D, level_bwd_pull_kernel, dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, G, h, ld, rows, n, D, out_net_indptr, out_net_indices, out_net_weight, out_cell_indptr, out_cell_indices, A, LSE, DA, relu);
   return check_launch("level_bwd_pull");
 }
 
@@ -253,9 +242,7 @@ int mmft_gather_rows(const float* src, long long lds, const int* idx, int n, int
                "gather_rows: rows must be 16-byte aligned");
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
-  ProfScope ps("gather_rows_kernel", 0.0, 2.0 * 4.0 * n * D, (hipStream_t)stream);
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(node_grid(n, D)), dim3(256), 0, (hipStream_t)stream, src, lds, idx, n, D,
-                     dst, ldd);
+  MMFT_LAUNCH("gather_rows_kernel", 0.0, 2.0 * 4.0 * n * D, gather_rows_kernel, dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, src, lds, idx, n, D, dst, ldd);
   return check_launch("gather_rows");
 }
 
@@ -267,9 +254,7 @@ int mmft_scatter_add_rows(float* dst, long long ldd, const int* idx, int n, int 
                "scatter_add_rows: rows must be 16-byte aligned");
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
-  ProfScope ps("scatter_add_rows_kernel", 0.0, 2.0 * 4.0 * n * D, (hipStream_t)stream);
-  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(node_grid(n, D)), dim3(256), 0, (hipStream_t)stream, dst, ldd, idx,
-                     n, D, src, lds);
+  MMFT_LAUNCH("scatter_add_rows_kernel", 0.0, 2.0 * 4.0 * n * D, scatter_add_rows_kernel, dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, dst, ldd, idx, n, D, src, lds);
   return check_launch("scatter_add_rows");
 }
 

@@ -48,6 +48,16 @@ void prof_begin(const char* name, double flops, double bytes, hipStream_t st) {
   g_open = ProfRec{name, flops, bytes, prof_event(), prof_event()};
   (void)hipEventRecord(g_open.e0, st);
 }
+void prof_events(const char* name, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1) {
+  g_prof_mu.lock();
+  g_open = ProfRec{name, flops, bytes, prof_event(), prof_event()};
+  *e0 = g_open.e0;
+  *e1 = g_open.e1;
+}
+void prof_commit() {
+  g_recs.push_back(g_open);
+  g_prof_mu.unlock();
+}
 void prof_end(hipStream_t st) {
   (void)hipEventRecord(g_open.e1, st);
   g_recs.push_back(g_open);
@@ -336,8 +346,7 @@ int mmft_act_bwd(const float* dy, const float* y, float* dpre, long long n, int 
   MMFT_REQUIRE(dy && y && dpre && n >= 0, "act_bwd: bad args");
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
-  ProfScope ps("act_bwd_kernel", 0.0, 12.0 * n, (hipStream_t)stream);
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dpre, n, act, slope);
+  MMFT_LAUNCH("act_bwd_kernel", 0.0, 12.0 * n, act_bwd_kernel, dim3(ew_grid(n)), dim3(256), (hipStream_t)stream, dy, y, dpre, n, act, slope);
   return check_launch("act_bwd");
 }
 

@@ -258,7 +258,6 @@ extern "C" int mmft_sweep_fwd_persistent(float* h, float* A, float* LSE, float* 
   (void)hipMemsetAsync(error_flag, 0, sizeof(int), st);
   SweepFwdArgs a{h, A, LSE, HN, in_net_indptr, in_net_indices, in_cell_indptr, in_cell_indices, level_ptr, level_rows, L,
                  w1, b1, w2, b2, relu, counter, error_flag};
-  ProfScope ps("sweep_fwd_persistent_kernel", 0.0, 0.0, st);
-  hipLaunchKernelGGL(sweep_fwd_persistent_kernel, dim3(grid), dim3(256), 0, st, a);
+  MMFT_LAUNCH("sweep_fwd_persistent_kernel", 0.0, 0.0, sweep_fwd_persistent_kernel, dim3(grid), dim3(256), st, a);
   return check_launch("sweep_fwd_persistent");
 }
