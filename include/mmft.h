@@ -91,15 +91,19 @@ int mmft_act_fwd(const float* x, float* y, long long n, int act, float slope, in
  * (src/model.py:186-187) and the degree-bucketed UDF PathConv.cell_msg_reduce (src/model.py:113-116,
  * 202-204), plus the activation write-back and target gather (src/model.py:206-213).
  * CSR: indptr[N+1], indices[E]; "in" = in-edges by destination (col = source), "out" = out-edges by
- * source (col = destination).  `rows` lists the node ids of the current topological level.
+ * source (col = destination).  `rows` lists the node ids of the current topological level; rows == NULL means
+ * the contiguous id range row0 .. row0+n-1 (levels are contiguous after level-major renumbering, which removes one
+ * dependent load from every thread's chain).  alg_bytes (optional, 0 = unknown) is the algorithmic HBM byte count of
+ * the launch, recorded with it by the launch profiler for bench.py's roofline.
  * ------------------------------------------------------------------------------------------- */
 /* A[v][c] = sum_i softmax_i(h[u_i][c]) h[u_i][c];  LSE[v][c] = log sum_i exp(h[u_i][c])  (deg 0: A=0) */
 int mmft_seg_softmax_sum_fwd(const float* h, long long ldh, const int* in_indptr, const int* in_indices,
-                             const int* rows, int n, int D, float* A, float* LSE, long long lda,
-                             int device, void* stream);
+                             const int* rows, int row0, int n, int D, float* A, float* LSE, long long lda,
+                             long long alg_bytes, int device, void* stream);
 /* h[v] = act(h[v] + mean_{u->v} h[u])   (h[v] holds fc_net_self(x_net[v]) on entry; 0 for degree 0) */
 int mmft_seg_mean_add_act_fwd(float* h, long long ldh, const int* in_indptr, const int* in_indices,
-                              const int* rows, int n, int D, int relu, int device, void* stream);
+                              const int* rows, int row0, int n, int D, int relu, long long alg_bytes,
+                              int device, void* stream);
 /* out[i] (+)= sum over the CSR segment of rows[i] of src[u]  (deterministic segmented row sum; with
  * accumulate != 0 the result is added to out[rows[i]] in place) */
 int mmft_seg_sum_fwd(const float* src, long long lds, const int* indptr, const int* indices,
@@ -115,10 +119,10 @@ int mmft_seg_mean_fwd(const float* src, long long lds, const int* in_indptr, con
  *   G[v] = relu ? (h[v] > 0 ? gh : 0) : gh
  * G rows of later levels hold d(loss)/d(pre-activation), DA rows d(loss)/d(A); both must be zero for
  * nodes whose backward has not run. */
-int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows, int n, int D,
+int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows, int row0, int n, int D,
                         const int* out_net_indptr, const int* out_net_indices, const float* out_net_weight,
                         const int* out_cell_indptr, const int* out_cell_indices,
-                        const float* A, const float* LSE, const float* DA, int relu,
+                        const float* A, const float* LSE, const float* DA, int relu, long long alg_bytes,
                         int device, void* stream);
 /* Persistent forward sweep: ONE launch for levels 1..L-1 of a mini-batch (the L per-level PathConv.forward calls of
  * src/train.py:490-511).  h must hold the *_self MLP outputs of every node (level 0 already activated); levels

@@ -28,12 +28,12 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 __global__ void __launch_bounds__(256) seg_softmax_sum_fwd_kernel(const float* __restrict__ h, long long ldh,
                                                                   const int* __restrict__ indptr,
                                                                   const int* __restrict__ indices,
-                                                                  const int* __restrict__ rows, int n, int D,
-                                                                  float* __restrict__ A, float* __restrict__ LSE,
-                                                                  long long lda) {
+                                                                  const int* __restrict__ rows, int row0, int n,
+                                                                  int D, float* __restrict__ A,
+                                                                  float* __restrict__ LSE, long long lda) {
   MMFT_NODE_LOOP(n, D) {
     int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
-    int v = rows ? rows[i] : i;
+    int v = rows ? rows[i] : row0 + i;
     int e0 = indptr[v], e1 = indptr[v + 1];
     f32x4 mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
@@ -65,12 +65,12 @@ __global__ void __launch_bounds__(256) seg_softmax_sum_fwd_kernel(const float* _
 __global__ void __launch_bounds__(256) seg_mean_fwd_kernel(const float* __restrict__ src, long long lds,
                                                            const int* __restrict__ indptr,
                                                            const int* __restrict__ indices,
-                                                           const int* __restrict__ rows, int n, int D,
+                                                           const int* __restrict__ rows, int row0, int n, int D,
                                                            float* __restrict__ out, long long ldo, int add_self,
                                                            int relu, int do_mean) {
   MMFT_NODE_LOOP(n, D) {
     int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
-    int v = rows ? rows[i] : i;
+    int v = rows ? rows[i] : row0 + i;
     int e0 = indptr[v], e1 = indptr[v + 1];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int e = e0; e < e1; ++e) acc += ld4(src + (long long)indices[e] * lds + c);
@@ -86,13 +86,13 @@ __global__ void __launch_bounds__(256) seg_mean_fwd_kernel(const float* __restri
 }
 
 __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
-    float* __restrict__ G, const float* __restrict__ h, long long ld, const int* __restrict__ rows, int n, int D,
-    const int* __restrict__ on_ptr, const int* __restrict__ on_idx, const float* __restrict__ on_w,
+    float* __restrict__ G, const float* __restrict__ h, long long ld, const int* __restrict__ rows, int row0, int n,
+    int D, const int* __restrict__ on_ptr, const int* __restrict__ on_idx, const float* __restrict__ on_w,
     const int* __restrict__ oc_ptr, const int* __restrict__ oc_idx, const float* __restrict__ A,
     const float* __restrict__ LSE, const float* __restrict__ DA, int relu) {
   MMFT_NODE_LOOP(n, D) {
     int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
-    int v = rows ? rows[i] : i;
+    int v = rows ? rows[i] : row0 + i;
     long long off = (long long)v * ld + c;
     f32x4 hv = ld4(h + off);
     f32x4 g = ld4(G + off);
@@ -170,8 +170,8 @@ using namespace mmft;
 extern "C" {
 
 int mmft_seg_softmax_sum_fwd(const float* h, long long ldh, const int* in_indptr, const int* in_indices,
-                             const int* rows, int n, int D, float* A, float* LSE, long long lda, int device,
-                             void* stream) {
+                             const int* rows, int row0, int n, int D, float* A, float* LSE, long long lda,
+                             long long alg_bytes, int device, void* stream) {
   CHECK_ROWS("seg_softmax_sum_fwd");
   MMFT_REQUIRE(h && in_indptr && A, "seg_softmax_sum_fwd: null pointer");
   MMFT_REQUIRE(ldh >= D && lda >= D && ldh % 4 == 0 && lda % 4 == 0 && aligned16(h) && aligned16(A) &&
@@ -179,18 +179,22 @@ int mmft_seg_softmax_sum_fwd(const float* h, long long ldh, const int* in_indptr
                "seg_softmax_sum_fwd: rows must be 16-byte aligned");
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
-  MMFT_LAUNCH("seg_softmax_sum_fwd_kernel", 0.0, 3.0 * 4.0 * n * D, seg_softmax_sum_fwd_kernel, dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, h, ldh, in_indptr, in_indices, rows, n, D, A, LSE, lda);
+  MMFT_LAUNCH("seg_softmax_sum_fwd_kernel", 0.0, alg_bytes > 0 ? (double)alg_bytes : 3.0 * 4.0 * n * D,
+              seg_softmax_sum_fwd_kernel, dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, h, ldh, in_indptr,
+              in_indices, rows, row0, n, D, A, LSE, lda);
   return check_launch("seg_softmax_sum_fwd");
 }
 
 int mmft_seg_mean_add_act_fwd(float* h, long long ldh, const int* in_indptr, const int* in_indices, const int* rows,
-                              int n, int D, int relu, int device, void* stream) {
+                              int row0, int n, int D, int relu, long long alg_bytes, int device, void* stream) {
   CHECK_ROWS("seg_mean_add_act_fwd");
   MMFT_REQUIRE(h && in_indptr, "seg_mean_add_act_fwd: null pointer");
   MMFT_REQUIRE(ldh >= D && ldh % 4 == 0 && aligned16(h), "seg_mean_add_act_fwd: rows must be 16-byte aligned");
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
-  MMFT_LAUNCH("seg_mean_fwd_kernel", 0.0, 3.0 * 4.0 * n * D, seg_mean_fwd_kernel, dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, h, ldh, in_indptr, in_indices, rows, n, D, h, ldh, 1, relu, 1);
+  MMFT_LAUNCH("seg_mean_fwd_kernel", 0.0, alg_bytes > 0 ? (double)alg_bytes : 3.0 * 4.0 * n * D, seg_mean_fwd_kernel,
+              dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, h, ldh, in_indptr, in_indices, rows, row0, n, D, h,
+              ldh, 1, relu, 1);
   return check_launch("seg_mean_add_act_fwd");
 }
 
@@ -202,7 +206,7 @@ int mmft_seg_mean_fwd(const float* src, long long lds, const int* in_indptr, con
                "seg_mean_fwd: rows must be 16-byte aligned");
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
-  MMFT_LAUNCH("seg_mean_fwd_kernel", 0.0, 3.0 * 4.0 * n * D, seg_mean_fwd_kernel, dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, src, lds, in_indptr, in_indices, rows, n, D, out, ldo, 0, 0, 1);
+  MMFT_LAUNCH("seg_mean_fwd_kernel", 0.0, 3.0 * 4.0 * n * D, seg_mean_fwd_kernel, dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, src, lds, in_indptr, in_indices, rows, 0, n, D, out, ldo, 0, 0, 1);
   return check_launch("seg_mean_fwd");
 }
 
@@ -214,14 +218,14 @@ int mmft_seg_sum_fwd(const float* src, long long lds, const int* indptr, const i
                "seg_sum_fwd: rows must be 16-byte aligned");
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
-  MMFT_LAUNCH("seg_mean_fwd_kernel", 0.0, 3.0 * 4.0 * n * D, seg_mean_fwd_kernel, dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, src, lds, indptr, indices, rows, n, D, out, ldo, accumulate ? 1 : 0, 0, 0);
+  MMFT_LAUNCH("seg_mean_fwd_kernel", 0.0, 3.0 * 4.0 * n * D, seg_mean_fwd_kernel, dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, src, lds, indptr, indices, rows, 0, n, D, out, ldo, accumulate ? 1 : 0, 0, 0);
   return check_launch("seg_sum_fwd");
 }
 
-int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows, int n, int D,
+int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows, int row0, int n, int D,
                         const int* out_net_indptr, const int* out_net_indices, const float* out_net_weight,
                         const int* out_cell_indptr, const int* out_cell_indices, const float* A, const float* LSE,
-                        const float* DA, int relu, int device, void* stream) {
+                        const float* DA, int relu, long long alg_bytes, int device, void* stream) {
   CHECK_ROWS("level_bwd_pull");
   MMFT_REQUIRE(G && h && out_net_indptr && out_cell_indptr && A && LSE && DA,
                "level_bwd_pull: null pointer");
@@ -230,7 +234,9 @@ int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows,
                "level_bwd_pull: rows must be 16-byte aligned");
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
-  MMFT_LAUNCH("level_bwd_pull_kernel", 0.0, 3.0 * 4.0 * n * D, level_bwd_pull_kernel, dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, G, h, ld, rows, n, D, out_net_indptr, out_net_indices, out_net_weight, out_cell_indptr, out_cell_indices, A, LSE, DA, relu);
+  MMFT_LAUNCH("level_bwd_pull_kernel", 0.0, alg_bytes > 0 ? (double)alg_bytes : 3.0 * 4.0 * n * D, level_bwd_pull_kernel,
+              dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, G, h, ld, rows, row0, n, D, out_net_indptr,
+              out_net_indices, out_net_weight, out_cell_indptr, out_cell_indices, A, LSE, DA, relu);
   return check_launch("level_bwd_pull");
 }
 

@@ -223,26 +223,38 @@ def _csr(indptr, indices, n_nodes, name):
     _idx(indices, name + '.indices')
 
 
-def seg_softmax_sum_fwd(h, in_csr, rows, A, LSE=None):
+def _rowspec(rows, N, name):
+    """rows: int32 device tensor | (start, n) contiguous range | None (all rows) -> (tensor or None, row0, n)."""
+    if rows is None:
+        return None, 0, N
+    if isinstance(rows, tuple):
+        start, n = int(rows[0]), int(rows[1])
+        if start < 0 or n < 0 or start + n > N:
+            raise ValueError(f'{name}: row range outside the node set')
+        return None, start, n
+    _idx(rows, name)
+    return rows, 0, rows.numel()
+
+
+def seg_softmax_sum_fwd(h, in_csr, rows, A, LSE=None, alg_bytes=0):
     _rows2d(h, 'h'); _rows2d(A, 'A')
     _csr(in_csr[0], in_csr[1], h.shape[0], 'in_csr')
-    _idx(rows, 'rows')
     if A.shape != h.shape or (LSE is not None and (LSE.shape != h.shape or LSE.stride(0) != A.stride(0))):
         raise ValueError('seg_softmax_sum_fwd: A/LSE must match h')
-    n = rows.numel() if rows is not None else h.shape[0]
+    rt, row0, n = _rowspec(rows, h.shape[0], 'rows')
     dev, st = lib.stream_args(h)
-    lib.call('mmft_seg_softmax_sum_fwd', h, h.stride(0), in_csr[0], in_csr[1], rows, n, h.shape[1], A, LSE,
-             A.stride(0), dev, st)
+    lib.call('mmft_seg_softmax_sum_fwd', h, h.stride(0), in_csr[0], in_csr[1], rt, row0, n, h.shape[1], A, LSE,
+             A.stride(0), int(alg_bytes), dev, st)
     return A
 
 
-def seg_mean_add_act_fwd(h, in_csr, rows, relu=True):
+def seg_mean_add_act_fwd(h, in_csr, rows, relu=True, alg_bytes=0):
     _rows2d(h, 'h')
     _csr(in_csr[0], in_csr[1], h.shape[0], 'in_csr')
-    _idx(rows, 'rows')
-    n = rows.numel() if rows is not None else h.shape[0]
+    rt, row0, n = _rowspec(rows, h.shape[0], 'rows')
     dev, st = lib.stream_args(h)
-    lib.call('mmft_seg_mean_add_act_fwd', h, h.stride(0), in_csr[0], in_csr[1], rows, n, h.shape[1], int(relu), dev, st)
+    lib.call('mmft_seg_mean_add_act_fwd', h, h.stride(0), in_csr[0], in_csr[1], rt, row0, n, h.shape[1], int(relu),
+             int(alg_bytes), dev, st)
     return h
 
 
@@ -271,7 +283,7 @@ def scatter_add_rows_det(dst, idx, src):
     return dst
 
 
-def level_bwd_pull(G, h, rows, out_net, out_net_w, out_cell, A, LSE, DA, relu=True):
+def level_bwd_pull(G, h, rows, out_net, out_net_w, out_cell, A, LSE, DA, relu=True, alg_bytes=0):
     for t, nm in ((G, 'G'), (h, 'h'), (A, 'A'), (LSE, 'LSE'), (DA, 'DA')):
         _rows2d(t, nm)
         if t.shape != h.shape or t.stride(0) != h.stride(0):
@@ -281,11 +293,10 @@ def level_bwd_pull(G, h, rows, out_net, out_net_w, out_cell, A, LSE, DA, relu=Tr
     _chk(out_net_w, 'out_net_w')
     if out_net_w.numel() != out_net[1].numel() or not out_net_w.is_contiguous():
         raise ValueError('level_bwd_pull: one weight per out-net edge expected')
-    _idx(rows, 'rows')
-    n = rows.numel() if rows is not None else N
+    rt, row0, n = _rowspec(rows, N, 'rows')
     dev, st = lib.stream_args(h)
-    lib.call('mmft_level_bwd_pull', G, h, h.stride(0), rows, n, h.shape[1], out_net[0], out_net[1], out_net_w,
-             out_cell[0], out_cell[1], A, LSE, DA, int(relu), dev, st)
+    lib.call('mmft_level_bwd_pull', G, h, h.stride(0), rt, row0, n, h.shape[1], out_net[0], out_net[1], out_net_w,
+             out_cell[0], out_cell[1], A, LSE, DA, int(relu), int(alg_bytes), dev, st)
     return G
 
 

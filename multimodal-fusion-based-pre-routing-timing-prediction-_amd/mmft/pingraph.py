@@ -179,6 +179,28 @@ class PinGraph:
         self._level_cache[key] = (ref, dev)
         return dev
 
+    def level_meta(self, level_id, nodes, D=128):
+        """Static facts about a level, cached: `range` = (start, n) when the node list is the contiguous ascending
+        id range start..start+n-1 (true after level-major renumbering), else None; algorithmic HBM bytes of the
+        level's aggregation kernels at width D (SURVEY.md §8d formulas, fp32)."""
+        key = ('meta', level_id, D)
+        hit = self._level_cache.get(key)
+        if hit is not None and (hit[0] is nodes or (len(hit[0]) == len(nodes) and hit[0] == nodes)):
+            return hit[1]
+        v = np.asarray(nodes, dtype=np.int64)
+        n = int(v.shape[0])
+        rng = None
+        if n and int(v[0]) + n - 1 == int(v[-1]) and (n == 1 or bool((np.diff(v) == 1).all())):
+            rng = (int(v[0]), n)
+        deg = lambda d, et: int((self._csr_host[(d, et)][0][v + 1] - self._csr_host[(d, et)][0][v]).sum()) if n else 0
+        e_in_net, e_in_cell, e_out_net, e_out_cell = deg('in', 'net'), deg('in', 'cell'), deg('out', 'net'), deg('out', 'cell')
+        meta = dict(range=rng, n=n,
+                    bytes_mean=4 * D * (e_in_net + 2 * n) + 4 * e_in_net + 8 * n,
+                    bytes_softmax=4 * D * (e_in_cell + 3 * n) + 4 * e_in_cell + 8 * n,
+                    bytes_pull=4 * D * (e_out_net + 3 * e_out_cell + 3 * n) + 8 * e_out_net + 4 * e_out_cell + 16 * n)
+        self._level_cache[key] = (nodes, meta)
+        return meta
+
     # ------------------------------------------------------------------ construction helpers
     @staticmethod
     def from_synth(d, out_dim=None):

@@ -50,6 +50,7 @@ class SweepState:
         self.HS = self._buf('HS', self.Hd)
         self.HN = self._buf('HN', self.Hd)
         self.G = self.DA = self.DHN = None
+        self.level_meta = None      # per-level static facts (contiguous range, algorithmic bytes), whole-sweep entry
         self.levels = []            # (level_id, rows) in forward order
         self.token = None
         self.next_level = 0
@@ -311,10 +312,12 @@ class SweepFn(torch.autograd.Function):
         for level_id, rows in enumerate(level_rows):
             if persistent or level_id == 0 or not rows.numel():
                 continue
+            meta = st.level_meta[level_id] if st.level_meta else None
+            spec = meta['range'] if (meta and meta['range']) else rows       # contiguous levels: no index array
             if level_id % 2 == 1:
-                ops.seg_mean_add_act_fwd(st.h, in_net, rows, relu=st.relu)
+                ops.seg_mean_add_act_fwd(st.h, in_net, spec, relu=st.relu, alg_bytes=meta['bytes_mean'] if meta else 0)
             else:
-                ops.seg_softmax_sum_fwd(st.h, in_cell, rows, st.A, st.LSE)
+                ops.seg_softmax_sum_fwd(st.h, in_cell, spec, st.A, st.LSE, alg_bytes=meta['bytes_softmax'] if meta else 0)
                 _cell_neigh_fwd(st, rows, w1g, b1g, w2g, b2g, act)
         ctx.state, ctx.tix, ctx.nparams = st, tix, len(params)
         return ops.gather_rows(st.h, tix) if tix.numel() else st.h.new_zeros((0, st.D))
@@ -332,7 +335,10 @@ class SweepFn(torch.autograd.Function):
         for level_id, rows in reversed(st.levels):
             if not rows.numel():
                 continue
-            ops.level_bwd_pull(st.G, st.h, rows, out_net, in_net_ptr, out_cell, st.A, st.LSE, st.DA, relu=st.relu)
+            meta = st.level_meta[level_id] if st.level_meta else None
+            spec = meta['range'] if (meta and meta['range']) else rows
+            ops.level_bwd_pull(st.G, st.h, spec, out_net, in_net_ptr, out_cell, st.A, st.LSE, st.DA, relu=st.relu,
+                               alg_bytes=meta['bytes_pull'] if meta else 0)
             if level_id % 2 == 0 and level_id > 0:
                 _cell_neigh_bwd(st, rows, w1g, w2g, keep_dhn=True)
         grads = _batched_param_grads(st, P, dhn_ready=True) if ctx.nparams else []
@@ -346,6 +352,8 @@ def sweep_forward_all(conv, graph, level_nodes, targets):
     st = SweepState(graph, conv)
     graph._sweep = st
     level_rows = [graph.level_rows(l, nodes, 'nodes') for l, nodes in enumerate(level_nodes)]
+    st.level_meta = [graph.level_meta(l, nodes, st.D) if not torch.is_tensor(nodes) else None
+                     for l, nodes in enumerate(level_nodes)]
     tix = graph.level_rows(-1, targets, 'sweep_targets')
     st.next_level = len(level_rows)
     if st.need_grad:
