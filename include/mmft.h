@@ -64,6 +64,12 @@ long long mmft_linear_wgrad_workspace_bytes(int rows, int out, int in);
 int mmft_linear_wgrad(const float* g, const int* gidx, long long ldg, const float* x, const int* xidx,
                       long long ldx, float* dw, long long lddw, int rows, int out, int in, int accumulate,
                       float* workspace, long long workspace_bytes, int device, void* stream);
+/* same GEMM, and db[o] (+)= sum_r g[gidx[r]][o] from the fragments of g the kernel already holds: weight AND bias
+ * gradient of one th.nn.Linear (src/model.py:13-14) from a single pass over g */
+long long mmft_linear_wgrad_bias_workspace_bytes(int rows, int out, int in);
+int mmft_linear_wgrad_bias(const float* g, const int* gidx, long long ldg, const float* x, const int* xidx,
+                           long long ldx, float* dw, long long lddw, float* db, int rows, int out, int in,
+                           int accumulate, float* workspace, long long workspace_bytes, int device, void* stream);
 /* Fused Linear-ReLU-Linear over gathered rows, hidden tile kept in LDS (one launch per cell level of the sweep;
  * PathConv.apply_cell_func's fc_cell_neigh, src/model.py:138-146, and its backward):
  *   hid = mask ? (x1[rows] . W1) * (mask[rows] > 0) : relu(x1[rows] . W1 + b1)

@@ -51,13 +51,14 @@ class DoubleConv(nn.Module):
         _channels_last_(self.double_conv[0])
         _channels_last_(self.double_conv[3])
         self.per_sample_stats = False
+        self.count_batches = True          # UNet bumps all num_batches_tracked counters with one launch instead
 
     def forward(self, x):
         dc = self.double_conv
         x = C.conv2d(x, dc[0].weight, None, pad=1)
-        x = C.bn_relu(x, dc[1], relu=True, per_sample=self.per_sample_stats)
+        x = C.bn_relu(x, dc[1], relu=True, per_sample=self.per_sample_stats, count=self.count_batches)
         x = C.conv2d(x, dc[3].weight, None, pad=1)
-        return C.bn_relu(x, dc[4], relu=True, per_sample=self.per_sample_stats)
+        return C.bn_relu(x, dc[4], relu=True, per_sample=self.per_sample_stats, count=self.count_batches)
 
 
 class Down(nn.Module):
@@ -122,6 +123,22 @@ class UNet(nn.Module):
         self.up2 = Up(64, 32 // factor, bilinear)
         self.up3 = Up(32, 16 // factor, bilinear)
         self.outc = OutConv(pooling_layer, 16, 1)
+        for m in self.modules():
+            if isinstance(m, DoubleConv):
+                m.count_batches = False
+
+    def _count_batches(self, n):
+        """num_batches_tracked += n for all 14 BatchNorm layers with ONE launch: the counters are kept as views of one
+        int64 vector (rebuilt whenever .to()/load replaced the buffer objects)."""
+        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
+        views = self.__dict__.get('_nbt_views')
+        if views is None or len(views) != len(bns) or any(b.num_batches_tracked is not v for b, v in zip(bns, views)):
+            flat = torch.stack([b.num_batches_tracked.reshape(()) for b in bns])
+            views = [flat[i] for i in range(len(bns))]
+            for b, v in zip(bns, views):
+                b._buffers['num_batches_tracked'] = v
+            self.__dict__['_nbt_flat'], self.__dict__['_nbt_views'] = flat, views
+        self.__dict__['_nbt_flat'] += n
 
     def set_per_sample_stats(self, flag=True):
         """BatchNorm statistics per image instead of per batch (used when several designs are batched)."""
@@ -133,6 +150,8 @@ class UNet(nn.Module):
     def forward(self, x):
         if x.dim() == 3:                       # train() feeds (C,H,W), validate()/test() (1,C,H,W): SURVEY D3
             x = x.unsqueeze(0)
+        per_sample = self.inc.per_sample_stats
+        self._count_batches(x.shape[0] if per_sample else 1)
         x1 = self.inc(x)
         x2 = self.down1(x1)
         x3 = self.down2(x2)

@@ -126,11 +126,20 @@ __global__ void __launch_bounds__(64) bn_finalize_kernel(const float* __restrict
   }
 }
 
-// running statistics: `groups` sequential momentum updates per channel (one per image when per-sample)
-__global__ void __launch_bounds__(256) bn_running_kernel(const float* __restrict__ save_mean, const float* __restrict__ save_var,
-                                                         int groups, long long rows, int C, float momentum,
-                                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
+// running statistics: `groups` sequential momentum updates per channel (one per image when per-sample).
+// Runs in block 0 of the apply kernel (C <= 256 = its block size): one launch less per layer.
+struct BnRunning {
+  const float* save_var;
+  float* running_mean;
+  float* running_var;
+  float momentum;
+  int groups;
+};
+
+__device__ __forceinline__ void bn_running_update(const float* __restrict__ save_mean, const float* __restrict__ save_var,
+                                                  int groups, long long rows, int C, float momentum,
+                                                  float* __restrict__ running_mean, float* __restrict__ running_var) {
+  int c = threadIdx.x;
   if (c >= C) return;
   double rm = (double)running_mean[c], rv = (double)running_var[c], n = (double)rows;
   for (int g = 0; g < groups; ++g) {
@@ -147,7 +156,9 @@ template <int VEC>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                       long long rows, int C, long long total, int relu) {
+                                                       long long rows, int C, long long total, int relu, BnRunning run) {
+  if (run.running_mean && blockIdx.x == 0)
+    bn_running_update(mean, run.save_var, run.groups, rows, C, run.momentum, run.running_mean, run.running_var);
   long long per_group = rows * C;
   for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VEC; i < total;
        i += (long long)gridDim.x * blockDim.x * VEC) {
@@ -254,9 +265,9 @@ __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const float* __rest
   }
 }
 
-__global__ void __launch_bounds__(256) bn_bwd_params_kernel(const float* __restrict__ coef, int groups, long long rows, int C,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void bn_bwd_params(const float* __restrict__ coef, int groups, long long rows, int C,
+                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  int c = threadIdx.x;
   if (c >= C) return;
   double dg = 0.0, db = 0.0;
   for (int g = 0; g < groups; ++g) {
@@ -272,7 +283,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ y, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, float* __restrict__ dx,
-                                                           long long rows, int C, long long total, int relu) {
+                                                           long long rows, int C, long long total, int relu, int groups,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  if (blockIdx.x == 0) bn_bwd_params(coef, groups, rows, C, dgamma, dbeta);
   long long per_group = rows * C;
   for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VEC; i < total;
        i += (long long)gridDim.x * blockDim.x * VEC) {
@@ -516,23 +529,21 @@ int mmft_bn_train_fwd(const float* x, float* y, const float* gamma, const float*
   DeviceGuard dg(device);
   hipStream_t st = (hipStream_t)stream;
   int bpg = bn_blocks(rows);
-  ProfScope ps("bn_train_fwd(4 kernels)", 0.0, 3.0 * 4.0 * groups * rows * C, st);
+  ProfScope ps("bn_train_fwd(3 kernels)", 0.0, 3.0 * 4.0 * groups * rows * C, st);
   const bool v4 = (C % 4 == 0) && aligned16(x) && aligned16(y);
   if (v4) hipLaunchKernelGGL(bn_partial_kernel<4>, dim3(groups * bpg), dim3(256), 0, st, x, rows, C, bpg, workspace);
   else hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(groups * bpg), dim3(256), 0, st, x, rows, C, bpg, workspace);
   float* save_var = workspace + (long long)groups * bpg * 2 * C;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(groups * C), dim3(64), 0, st, x, workspace, rows, C, bpg, eps, save_mean,
                      save_invstd, save_var);
-  if (running_mean && running_var)
-    hipLaunchKernelGGL(bn_running_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, save_mean, save_var, groups, rows, C,
-                       momentum, running_mean, running_var);
+  BnRunning run{save_var, (running_mean && running_var) ? running_mean : nullptr, running_var, momentum, groups};
   long long total = (long long)groups * rows * C;
   if (v4)
     hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(ew_grid(total / 4)), dim3(256), 0, st, x, y, gamma, beta, save_mean,
-                       save_invstd, rows, C, total, relu);
+                       save_invstd, rows, C, total, relu, run);
   else
     hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(ew_grid(total)), dim3(256), 0, st, x, y, gamma, beta, save_mean,
-                       save_invstd, rows, C, total, relu);
+                       save_invstd, rows, C, total, relu, run);
   return check_launch("bn_train_fwd");
 }
 
@@ -547,7 +558,7 @@ int mmft_bn_train_bwd(const float* gy, const float* x, const float* y, const flo
   hipStream_t st = (hipStream_t)stream;
   int bpg = bn_blocks(rows);
   float* coef = workspace + (long long)groups * bpg * 2 * C;
-  ProfScope ps("bn_train_bwd(4 kernels)", 0.0, 7.0 * 4.0 * groups * rows * C, st);
+  ProfScope ps("bn_train_bwd(3 kernels)", 0.0, 7.0 * 4.0 * groups * rows * C, st);
   const bool v4 = (C % 4 == 0) && aligned16(x) && aligned16(gy) && aligned16(dx) && (!y || aligned16(y));
   if (v4)
     hipLaunchKernelGGL(bn_bwd_partial_kernel<4>, dim3(groups * bpg), dim3(256), 0, st, gy, x, y, save_mean, save_invstd, rows,
@@ -556,14 +567,13 @@ int mmft_bn_train_bwd(const float* gy, const float* x, const float* y, const flo
     hipLaunchKernelGGL(bn_bwd_partial_kernel<1>, dim3(groups * bpg), dim3(256), 0, st, gy, x, y, save_mean, save_invstd, rows,
                        C, bpg, relu, workspace);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(groups * C), dim3(64), 0, st, workspace, rows, C, bpg, coef);
-  hipLaunchKernelGGL(bn_bwd_params_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, coef, groups, rows, C, dgamma, dbeta);
   long long total = (long long)groups * rows * C;
   if (v4)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_grid(total / 4)), dim3(256), 0, st, gy, x, y, gamma, save_mean,
-                       save_invstd, coef, dx, rows, C, total, relu);
+                       save_invstd, coef, dx, rows, C, total, relu, groups, dgamma, dbeta);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_grid(total)), dim3(256), 0, st, gy, x, y, gamma, save_mean,
-                       save_invstd, coef, dx, rows, C, total, relu);
+                       save_invstd, coef, dx, rows, C, total, relu, groups, dgamma, dbeta);
   return check_launch("bn_train_bwd");
 }
 

@@ -267,6 +267,11 @@ struct Epi {
   float slope;
   long long slab;      // split-K: C + z*slab
   int vec;
+  // optional by-product for weight-gradient GEMMs: colsum[z][m] (+)= sum_k X[m][k], i.e. the bias gradient of the same
+  // layer, accumulated from the fragments the n-tile-0 workgroups already hold (saves re-reading X in a second kernel)
+  float* colsum;
+  long long colsum_slab;
+  int colsum_accum;
 
   __device__ __forceinline__ float activate(float v) const {
     if (act == ACT_RELU) return v > 0.f ? v : 0.f;
@@ -393,6 +398,11 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(XL xl, WL wl, Epi epi, in
 #pragma unroll
     for (int b = 0; b < FT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const bool do_cs = epi.colsum != nullptr && blockIdx.y == 0 && wn == 0;      // wave-uniform
+  float cs[RT];
+#pragma unroll
+  for (int a = 0; a < RT; ++a) cs[a] = 0.f;
+
   f32x4 xr[XN], wr[WNL];
   auto gload = [&](int k0) {
 #pragma unroll
@@ -430,6 +440,10 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(XL xl, WL wl, Epi epi, in
       for (int a = 0; a < RT; ++a) read_frag<XL::KMAJOR, XS>(xs, (wm * RT + a) * 16, kb, lane, xf[a]);
 #pragma unroll
       for (int b = 0; b < FT; ++b) read_frag<WL::KMAJOR, WS>(ws, (wn * FT + b) * 16, kb, lane, wf[b]);
+      if (do_cs) {
+#pragma unroll
+        for (int a = 0; a < RT; ++a) cs[a] += (xf[a][0] + xf[a][1]) + (xf[a][2] + xf[a][3]);
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -451,6 +465,19 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(XL xl, WL wl, Epi epi, in
       int n = n0 + (wn * FT + b) * 16 + (lane >> 4) * 4;
       epi.store(m, n, acc[a][b], M, N, blockIdx.z);
     }
+  if (do_cs) {
+#pragma unroll
+    for (int a = 0; a < RT; ++a) {
+      float v = cs[a];                                  // lane quarter q holds the k = 4q..4q+3 share of row lane&15
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      int m = m0 + (wm * RT + a) * 16 + lane;
+      if (lane < 16 && m < M) {
+        float* q = epi.colsum + (long long)blockIdx.z * epi.colsum_slab + m;
+        *q = (epi.colsum_accum ? *q : 0.f) + v;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------ dispatch

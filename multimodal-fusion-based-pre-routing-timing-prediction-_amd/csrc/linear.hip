@@ -284,8 +284,14 @@ long long mmft_linear_wgrad_workspace_bytes(int rows, int out, int in) {
   return s > 1 ? (long long)s * out * in * 4 : 0;
 }
 
-int mmft_linear_wgrad(const float* g, const int* gidx, long long ldg, const float* x, const int* xidx, long long ldx,
-                      float* dw, long long lddw, int rows, int out, int in, int accumulate, float* workspace,
+long long mmft_linear_wgrad_bias_workspace_bytes(int rows, int out, int in) {
+  int s = wgrad_splits(rows, out, in);
+  return s > 1 ? (long long)s * ((long long)out * in + out) * 4 : 0;
+}
+
+// dw (+)= g^T x and, when db is given, db (+)= column sums of g from the same pass over g
+static int wgrad_impl(const float* g, const int* gidx, long long ldg, const float* x, const int* xidx, long long ldx,
+                      float* dw, long long lddw, float* db, int rows, int out, int in, int accumulate, float* workspace,
                       long long workspace_bytes, int device, void* stream) {
   MMFT_REQUIRE(g && x && dw, "linear_wgrad: null pointer");
   MMFT_REQUIRE(rows >= 0 && out > 0 && in > 0, "linear_wgrad: bad sizes");
@@ -296,6 +302,7 @@ int mmft_linear_wgrad(const float* g, const int* gidx, long long ldg, const floa
   if (rows == 0) {
     if (!accumulate) {
       for (int o = 0; o < out; ++o) (void)hipMemsetAsync(dw + (long long)o * lddw, 0, (size_t)in * 4, st);
+      if (db) (void)hipMemsetAsync(db, 0, (size_t)out * 4, st);
     }
     return MMFT_OK;
   }
@@ -305,17 +312,35 @@ int mmft_linear_wgrad(const float* g, const int* gidx, long long ldg, const floa
   if (splits <= 1 || lddw != in) {
     // single pass straight into dw (also the path for strided dw, where slabs would not line up)
     Epi epi{dw, lddw, nullptr, nullptr, nullptr, nullptr, 0, accumulate ? EPI_ACCUM : EPI_STORE, ACT_NONE, 0.f, 0,
-            (lddw % 4 == 0) && aligned16(dw)};
+            (lddw % 4 == 0) && aligned16(dw), db, 0, accumulate};
     return launch_gemm(xl, wl, epi, out, in, rows, 1, st);
   }
-  long long need = (long long)splits * out * in * 4;
+  long long need = (long long)splits * ((long long)out * in + (db ? out : 0)) * 4;
   MMFT_REQUIRE(workspace && workspace_bytes >= need, "linear_wgrad: workspace too small (%lld < %lld)", workspace_bytes,
                need);
+  float* cs_slabs = db ? workspace + (long long)splits * out * in : nullptr;
   Epi epi{workspace, in, nullptr, nullptr, nullptr, nullptr, 0, EPI_STORE, ACT_NONE, 0.f, (long long)out * in,
-          (in % 4 == 0) && aligned16(workspace)};
+          (in % 4 == 0) && aligned16(workspace), cs_slabs, out, 0};
   int rc = launch_gemm(xl, wl, epi, out, in, rows, splits, st);
   if (rc) return rc;
-  return launch_slab_reduce(workspace, splits, (long long)out * in, dw, accumulate, st);
+  rc = launch_slab_reduce(workspace, splits, (long long)out * in, dw, accumulate, st);
+  if (rc || !db) return rc;
+  return launch_slab_reduce(cs_slabs, splits, out, db, accumulate, st);
+}
+
+int mmft_linear_wgrad(const float* g, const int* gidx, long long ldg, const float* x, const int* xidx, long long ldx,
+                      float* dw, long long lddw, int rows, int out, int in, int accumulate, float* workspace,
+                      long long workspace_bytes, int device, void* stream) {
+  return wgrad_impl(g, gidx, ldg, x, xidx, ldx, dw, lddw, nullptr, rows, out, in, accumulate, workspace, workspace_bytes,
+                    device, stream);
+}
+
+int mmft_linear_wgrad_bias(const float* g, const int* gidx, long long ldg, const float* x, const int* xidx, long long ldx,
+                           float* dw, long long lddw, float* db, int rows, int out, int in, int accumulate,
+                           float* workspace, long long workspace_bytes, int device, void* stream) {
+  MMFT_REQUIRE(db, "linear_wgrad_bias: null bias-gradient pointer");
+  return wgrad_impl(g, gidx, ldg, x, xidx, ldx, dw, lddw, db, rows, out, in, accumulate, workspace, workspace_bytes,
+                    device, stream);
 }
 
 long long mmft_colsum_workspace_bytes(int rows, int cols) { return (long long)colsum_blocks(rows) * cols * 4; }

@@ -5,7 +5,7 @@ Every op takes and returns (N,C,H,W)-shaped tensors whose memory is NHWC; inputs
 are converted once by the HIP layout kernel.
 """
 import torch
-from . import ops
+from . import ops, gradsink
 from .ops import POOL_MAX, POOL_AVG  # noqa: F401
 
 
@@ -19,6 +19,7 @@ class Conv2dFn(torch.autograd.Function):
         y = ops.conv2d_fwd(xn, w, b, pad, act, sl)
         ctx.pad, ctx.act, ctx.slope = pad, act, sl
         ctx.has_bias = b is not None
+        ctx.sinks = (gradsink.of(w), gradsink.of(b))
         ctx.save_for_backward(xn, w, y if act != ops.ACT_NONE else None)
         return y
 
@@ -32,9 +33,12 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_dgrad(g, w, ctx.pad)
         if ctx.needs_input_grad[1]:
-            dw = ops.conv2d_wgrad(xn, g, w.shape[2], w.shape[3], ctx.pad)
+            dw = gradsink.deliver(ctx.sinks[0] if ops.is_nhwc(w) else None,
+                                  lambda out: ops.conv2d_wgrad(xn, g, w.shape[2], w.shape[3], ctx.pad, out=out),
+                                  shape=(w.shape[0], w.shape[2], w.shape[3], w.shape[1]))
+            dw = dw.permute(0, 3, 1, 2) if dw is not None else None          # [Co][KH][KW][Ci] memory -> OIHW shape
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.colsum(ops.rows_view(g))
+            db = gradsink.deliver(ctx.sinks[1], lambda out: ops.colsum(ops.rows_view(g), out=out))
         return dx, dw, db, None, None
 
 
@@ -51,21 +55,28 @@ class BnReluFn(torch.autograd.Function):
         y, mean, invstd = ops.bn_train_fwd(xn, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps,
                                            relu, per_sample)
         ctx.relu = relu
+        ctx.sinks = (gradsink.of(gamma), gradsink.of(beta))
         ctx.save_for_backward(xn, y, gamma, mean, invstd)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         xn, y, gamma, mean, invstd = ctx.saved_tensors
-        dx, dgamma, dbeta = ops.bn_train_bwd(ops.to_nhwc(gy), xn, y, gamma.detach(), mean, invstd, ctx.relu)
+        sg, sb = ctx.sinks
+        both = sg is not None and sb is not None and gradsink.fresh(sg) and gradsink.fresh(sb)
+        outs = (gradsink.take(sg), gradsink.take(sb)) if both else (None, None)
+        dx, dgamma, dbeta = ops.bn_train_bwd(ops.to_nhwc(gy), xn, y, gamma.detach(), mean, invstd, ctx.relu,
+                                             dgamma=outs[0], dbeta=outs[1])
+        if both:
+            dgamma = dbeta = None
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
-def bn_relu(x, bn, relu=True, per_sample=False):
+def bn_relu(x, bn, relu=True, per_sample=False, count=True):
     """`bn` is an nn.BatchNorm2d holding the parameters/buffers; always batch statistics."""
     if bn.momentum is None or not bn.affine:
         raise NotImplementedError('BatchNorm2d without momentum/affine is not on the reference path')
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
+    if count and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += x.shape[0] if per_sample else 1
     return BnReluFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu, per_sample)
 
@@ -142,6 +153,7 @@ class ConvT2x2Fn(torch.autograd.Function):
         t = ops.linear_fwd(ops.rows_view(xn), _wr(w), None)
         y = ops.pixel_shuffle2(t, b, N, H, W, Co)
         ctx.has_bias = b is not None
+        ctx.sinks = (gradsink.of(w), gradsink.of(b))
         ctx.save_for_backward(xn, w)
         return y
 
@@ -156,10 +168,13 @@ class ConvT2x2Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.linear_dgrad(gu, _wr(w)).reshape(N, H, W, Ci).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            dwr = ops.linear_wgrad(gu, ops.rows_view(xn))  # [(a,b,co)][ci]
-            dw = dwr.reshape(2, 2, Co, Ci).permute(3, 2, 0, 1)
+            # the sink is usable when the parameter is stored in (a,b,co,ci) order (Unet.Up keeps it that way)
+            sw = ctx.sinks[0] if w.permute(2, 3, 1, 0).is_contiguous() else None
+            dwr = gradsink.deliver(sw, lambda out: ops.linear_wgrad(gu, ops.rows_view(xn), dw=out),
+                                   shape=(4 * Co, Ci))                                            # [(a,b,co)][ci]
+            dw = dwr.reshape(2, 2, Co, Ci).permute(3, 2, 0, 1) if dwr is not None else None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.colsum(ops.rows_view(g))
+            db = gradsink.deliver(ctx.sinks[1], lambda out: ops.colsum(ops.rows_view(g), out=out))
         return dx, dw, db
 
 

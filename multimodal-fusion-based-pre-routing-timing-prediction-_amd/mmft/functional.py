@@ -5,7 +5,7 @@ taken from the tensors / current stream at call time, and `backward(retain_graph
 (reference src/train.py:553) is tolerated because nothing is freed or mutated in backward.
 """
 import torch
-from . import ops
+from . import ops, gradsink
 
 
 class LinearActFn(torch.autograd.Function):
@@ -21,6 +21,7 @@ class LinearActFn(torch.autograd.Function):
         y = ops.linear_fwd(x2, wc, b, act=act, slope=sl)
         ctx.act, ctx.slope, ctx.xshape = act, sl, x.shape
         ctx.has_bias = b is not None
+        ctx.sinks = (gradsink.of(w) if wc is w else None, gradsink.of(b))
         ctx.save_for_backward(x2, wc, y)
         return y.reshape(*x.shape[:-1], w.shape[0])
 
@@ -35,10 +36,14 @@ class LinearActFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = ops.linear_dgrad(g, w).reshape(ctx.xshape)
-        if ctx.needs_input_grad[1]:
-            dw = ops.linear_wgrad(g, x2)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.colsum(g)
+        if ctx.needs_input_grad[1] and ctx.has_bias and ctx.needs_input_grad[2]:
+            # weight and bias gradient from one pass over g
+            dw, db = gradsink.deliver_pair(ctx.sinks[0], ctx.sinks[1],
+                                           lambda ow, ob: ops.linear_wgrad(g, x2, dw=ow, db=ob, with_bias=True))
+        elif ctx.needs_input_grad[1]:
+            dw = gradsink.deliver(ctx.sinks[0], lambda out: ops.linear_wgrad(g, x2, dw=out))
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
+            db = gradsink.deliver(ctx.sinks[1], lambda out: ops.colsum(g, out=out))
         return dx, dw, db, None
 
 

@@ -8,7 +8,7 @@ GEMM kernel.
 """
 import numpy as np
 import torch
-from . import lib, ops
+from . import lib, ops, gradsink
 
 
 def _csc_from_csr(indptr, cols, P):
@@ -121,6 +121,7 @@ class MaskedFcFn(torch.autograd.Function):
                  dev, st)
         ctx.pm, ctx.fshape = pm, feat_map.shape
         ctx.has_bias = b is not None
+        ctx.sinks = (gradsink.of(w) if wc is w else None, gradsink.of(b))
         ctx.save_for_backward(f, wT)
         return out
 
@@ -137,11 +138,15 @@ class MaskedFcFn(torch.autograd.Function):
         ws = lib.workspace(f.device, B * P * Dout * 4 if B > 1 else 0)
         lib.call('mmft_masked_fc_bwd', pm.masks.csc_indptr, pm.masks.csc_paths, pm.first, pm.next, g, f, wT, dwT, df,
                  B, P, Dout, ws, ws.numel() * 4, dev, st)
-        dw = None
+        dw = db = None
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((Dout, P), dtype=torch.float32, device=f.device)
-            lib.call('mmft_transpose', dwT, dw, P, Dout, dev, st)
-        db = ops.colsum(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            def _dw(out):
+                out = torch.empty((Dout, P), dtype=torch.float32, device=f.device) if out is None else out
+                lib.call('mmft_transpose', dwT, out, P, Dout, dev, st)
+                return out
+            dw = gradsink.deliver(ctx.sinks[0], _dw)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = gradsink.deliver(ctx.sinks[1], lambda out: ops.colsum(g, out=out))
         return (df.reshape(ctx.fshape) if ctx.needs_input_grad[0] else None, dw, db, None)
 
 
@@ -222,9 +227,11 @@ class FlatAdam:
             view.copy_(src)
             p.data = view
             p.grad = torch.as_strided(self.flat_grad, view.shape, view.stride(), o)
+            gradsink.attach(p, p.grad)          # backward kernels store into the flat buffer directly
 
     def zero_grad(self):
         self.flat_grad.zero_()
+        gradsink.new_step()
 
     def step(self, gscale=1.0):
         self.step_count += 1

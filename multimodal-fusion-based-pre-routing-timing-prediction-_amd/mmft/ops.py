@@ -106,8 +106,9 @@ def linear_dgrad(g, w, dx=None, gidx=None, dxidx=None, M=None, mask=None, maskid
     return dx
 
 
-def linear_wgrad(g, x, dw=None, gidx=None, xidx=None, rows=None, accumulate=False):
-    """dw[o][i] (+)= sum_r g[gidx[r]][o] * x[xidx[r]][i]."""
+def linear_wgrad(g, x, dw=None, gidx=None, xidx=None, rows=None, accumulate=False, db=None, with_bias=False):
+    """dw[o][i] (+)= sum_r g[gidx[r]][o] * x[xidx[r]][i]; with_bias (or db given): also db[o] (+)= sum_r g[gidx[r]][o]
+    from the same pass, and the pair (dw, db) is returned."""
     _rows2d(g, 'g'); _rows2d(x, 'x')
     out, inn = g.shape[1], x.shape[1]
     if rows is None:
@@ -121,9 +122,18 @@ def linear_wgrad(g, x, dw=None, gidx=None, xidx=None, rows=None, accumulate=Fals
     _rows2d(dw, 'dw')
     if tuple(dw.shape) != (out, inn):
         raise ValueError(f'linear_wgrad: dw shape {tuple(dw.shape)} != {(out, inn)}')
-    need = lib.query('mmft_linear_wgrad_workspace_bytes', rows, out, inn)
-    ws = lib.workspace(g.device, need)
     dev, st = lib.stream_args(g)
+    if with_bias or db is not None:
+        if db is None:
+            db = torch.empty(out, dtype=torch.float32, device=g.device)
+        _chk(db, 'db')
+        if db.numel() != out or not db.is_contiguous():
+            raise ValueError('linear_wgrad: db shape')
+        ws = lib.workspace(g.device, lib.query('mmft_linear_wgrad_bias_workspace_bytes', rows, out, inn))
+        lib.call('mmft_linear_wgrad_bias', g, gidx, g.stride(0), x, xidx, x.stride(0), dw, dw.stride(0), db, rows, out,
+                 inn, int(accumulate), ws, ws.numel() * 4, dev, st)
+        return dw, db
+    ws = lib.workspace(g.device, lib.query('mmft_linear_wgrad_workspace_bytes', rows, out, inn))
     lib.call('mmft_linear_wgrad', g, gidx, g.stride(0), x, xidx, x.stride(0), dw, dw.stride(0), rows, out, inn,
              int(accumulate), ws, ws.numel() * 4, dev, st)
     return dw
@@ -395,19 +405,22 @@ def conv2d_dgrad(gy, w, pad):
     return dx
 
 
-def conv2d_wgrad(x, gy, KH, KW, pad):
-    """returns dw as an OIHW-shaped view over [Co][KH][KW][Ci] memory."""
+def conv2d_wgrad(x, gy, KH, KW, pad, out=None):
+    """returns dw as a contiguous [Co][KH][KW][Ci] tensor (`out` when given)."""
     _nhwc(x, 'x'); _nhwc(gy, 'gy')
     N, Ci, H, W = x.shape
     Co = gy.shape[1]
     if gy.shape[0] != N or gy.shape[2:] != x.shape[2:]:
         raise ValueError('conv2d_wgrad: shape mismatch')
-    dw = torch.empty((Co, KH, KW, Ci), dtype=torch.float32, device=x.device)
+    dw = out if out is not None else torch.empty((Co, KH, KW, Ci), dtype=torch.float32, device=x.device)
+    _chk(dw, 'dw')
+    if tuple(dw.shape) != (Co, KH, KW, Ci) or not dw.is_contiguous():
+        raise ValueError(f'conv2d_wgrad: out must be a contiguous {(Co, KH, KW, Ci)} tensor')
     need = lib.query('mmft_conv2d_wgrad_workspace_bytes', N, H, W, Ci, Co, KH, KW)
     ws = lib.workspace(x.device, need)
     dev, st = lib.stream_args(x)
     lib.call('mmft_conv2d_wgrad', x, gy, dw, N, H, W, Ci, Co, KH, KW, pad, ws, ws.numel() * 4, dev, st)
-    return dw.permute(0, 3, 1, 2)
+    return dw
 
 
 def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu, per_sample=False):
@@ -428,14 +441,18 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu,
     return y, mean, invstd
 
 
-def bn_train_bwd(gy, x, y, gamma, mean, invstd, relu):
+def bn_train_bwd(gy, x, y, gamma, mean, invstd, relu, dgamma=None, dbeta=None):
     _nhwc(gy, 'gy'); _nhwc(x, 'x')
     N, C, H, W = x.shape
     groups = mean.shape[0]
     rows = N * H * W // groups
     dx = empty_nhwc(N, C, H, W, x.device)
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if dgamma is None else dgamma
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if dbeta is None else dbeta
+    for t, nm in ((dgamma, 'dgamma'), (dbeta, 'dbeta')):
+        _chk(t, nm)
+        if t.numel() != C or not t.is_contiguous():
+            raise ValueError(f'bn_train_bwd: {nm} shape')
     ws = lib.workspace(x.device, lib.query('mmft_bn_workspace_bytes', groups, rows, C))
     dev, st = lib.stream_args(x)
     lib.call('mmft_bn_train_bwd', gy, x, y, gamma, mean, invstd, dx, dgamma, dbeta, groups, rows, C, int(relu), ws,

@@ -16,7 +16,7 @@ two small GEMMs that turn G into DA.  Weight gradients are NOT computed per leve
 (last to run) computes all of them in batched GEMMs over every node of the sweep.
 """
 import torch
-from . import ops
+from . import ops, gradsink
 
 _MLP_KEYS = ('fc_cell_self', 'fc_net_self', 'fc_cell_neigh')
 
@@ -181,31 +181,35 @@ def _cat_rows(st, pred):
     return sel[0] if len(sel) == 1 else torch.cat(sel)
 
 
-def _mlp_grads(st, G, gidx, H, X, xidx, w2, dH_rows=None):
-    """Gradients of one Linear-ReLU-Linear MLP over the rows `gidx`: (dW1, db1, dW2, db2).
+def _mlp_grads(st, sinks, G, gidx, H, X, xidx, w2, dH_rows=None):
+    """Gradients of one Linear-ReLU-Linear MLP over the rows `gidx`: (dW1, db1, dW2, db2); entries whose parameter
+    has a gradient sink (mmft.gradsink) are written there and returned as None.
     dH_rows: [N, Hd] buffer already holding the hidden gradients of those rows (from the level loop)."""
-    dW2 = ops.linear_wgrad(G, H, gidx=gidx, xidx=gidx)
-    db2 = ops.colsum(G, idx=gidx)
+    s1w, s1b, s2w, s2b = sinks
+    dW2, db2 = gradsink.deliver_pair(s2w, s2b, lambda ow, ob: ops.linear_wgrad(G, H, dw=ow, gidx=gidx, xidx=gidx, db=ob,
+                                                                               with_bias=True))
     if dH_rows is not None:
-        dW1 = ops.linear_wgrad(dH_rows, X, gidx=gidx, xidx=xidx)
-        db1 = ops.colsum(dH_rows, idx=gidx)
+        dW1, db1 = gradsink.deliver_pair(s1w, s1b, lambda ow, ob: ops.linear_wgrad(dH_rows, X, dw=ow, gidx=gidx,
+                                                                                   xidx=xidx, db=ob, with_bias=True))
     else:
         dH = ops.linear_dgrad(G, w2, gidx=gidx, mask=H, maskidx=gidx)
-        dW1 = ops.linear_wgrad(dH, X, xidx=xidx)
-        db1 = ops.colsum(dH)
+        dW1, db1 = gradsink.deliver_pair(s1w, s1b, lambda ow, ob: ops.linear_wgrad(dH, X, dw=ow, xidx=xidx, db=ob,
+                                                                                   with_bias=True))
     return [dW1, db1, dW2, db2]
 
 
 def _batched_param_grads(st, P, dhn_ready=False):
     (w1c, b1c, w2c, b2c, w1n, b1n, w2n, b2n, w1g, b1g, w2g, b2g) = P
+    # a sink is only usable when the kernel-side tensor IS the parameter's storage (contiguous weights)
+    S = [gradsink.of(p) if p.is_contiguous() else None for p in st.params]
     rc = _cat_rows(st, lambda l: l % 2 == 0)
     rn = _cat_rows(st, lambda l: l % 2 == 1)
     rc2 = _cat_rows(st, lambda l: l % 2 == 0 and l > 0)
     zeros = lambda ps: [torch.zeros_like(p) for p in ps]
-    gc = _mlp_grads(st, st.G, rc, st.HS, st.cell_feat, rc, w2c) if rc is not None else zeros(P[0:4])
-    gn = _mlp_grads(st, st.G, rn, st.HS, st.net_feat, rn, w2n) if rn is not None else zeros(P[4:8])
-    gg = _mlp_grads(st, st.G, rc2, st.HN, st.A, rc2, w2g, st.DHN if (dhn_ready and st.DHN is not None) else None) \
-        if rc2 is not None else zeros(P[8:12])
+    gc = _mlp_grads(st, S[0:4], st.G, rc, st.HS, st.cell_feat, rc, w2c) if rc is not None else zeros(P[0:4])
+    gn = _mlp_grads(st, S[4:8], st.G, rn, st.HS, st.net_feat, rn, w2n) if rn is not None else zeros(P[4:8])
+    gg = _mlp_grads(st, S[8:12], st.G, rc2, st.HN, st.A, rc2, w2g,
+                    st.DHN if (dhn_ready and st.DHN is not None) else None) if rc2 is not None else zeros(P[8:12])
     return gc + gn + gg
 
 

@@ -72,6 +72,13 @@ def test_linear_wgrad_colsum(dev, rows, out, inn):
     assert torch.equal(ops.linear_wgrad(g, x), dw)
     cs = ops.colsum(g)
     assert rel_err(cs, g.double().sum(0)) < TOL
+    # weight and bias gradient from one pass over g (column sums as a by-product of the n-tile-0 workgroups)
+    dw3, db3 = ops.linear_wgrad(g, x, with_bias=True)
+    assert torch.equal(dw3, dw)
+    assert rel_err(db3, g.double().sum(0)) < TOL
+    dw4, db4 = ops.linear_wgrad(g, x, dw=dw3.clone(), db=db3.clone(), accumulate=True)
+    assert rel_err(dw4, 2 * ref) < TOL and rel_err(db4, 2 * g.double().sum(0)) < TOL
+    assert torch.equal(ops.linear_wgrad(g, x, with_bias=True)[1], db3)
 
 
 def test_linear_wgrad_indexed(dev):
@@ -81,6 +88,8 @@ def test_linear_wgrad_indexed(dev):
     ref = g.double()[idx.long()].t() @ x.double()[idx.long()]
     assert rel_err(ops.linear_wgrad(g, x, gidx=idx, xidx=idx), ref) < TOL
     assert rel_err(ops.colsum(g, idx=idx), g.double()[idx.long()].sum(0)) < TOL
+    dw, db = ops.linear_wgrad(g, x, gidx=idx, xidx=idx, with_bias=True)
+    assert rel_err(dw, ref) < TOL and rel_err(db, g.double()[idx.long()].sum(0)) < TOL
 
 
 def test_act(dev):

@@ -295,6 +295,60 @@ def test_flat_adam_matches_torch(dev):
         close(q, p, 1e-6, 'adam')
 
 
+def test_gradient_sinks_shared_weights_and_second_backward(dev):
+    """mmft.gradsink: with FlatAdam the backward kernels store into the flat buffer.  A weight used twice in one
+    graph, a second backward without zero_grad (retain_graph, src/train.py:553) and a conv / BatchNorm / ConvT
+    stack must leave the same .grad as plain autograd accumulation (torch modules, fp64)."""
+    import torch.nn as nn
+    from mmft.fusion import FlatAdam
+    from mmft.functional import linear_act
+    from mmft import cnn as C
+    torch.manual_seed(11)
+    lin = nn.Linear(24, 24).to(dev)
+    conv = nn.Conv2d(4, 8, 3, padding=1).to(dev).to(memory_format=torch.channels_last)
+    bn = nn.BatchNorm2d(8).to(dev)
+    up = nn.ConvTranspose2d(8, 4, 2, stride=2).to(dev)
+    up.weight.data = up.weight.data.permute(2, 3, 1, 0).contiguous().permute(3, 2, 0, 1)
+    params = list(lin.parameters()) + list(conv.parameters()) + list(bn.parameters()) + list(up.parameters())
+    ref = [p.detach().double().clone().requires_grad_(True) for p in params]
+    x = torch.randn(50, 24, device=dev)
+    img = torch.randn(2, 4, 8, 8, device=dev)
+    opt = FlatAdam(params, lr=1e-3)
+
+    def mine():
+        y = linear_act(linear_act(x, lin.weight, lin.bias, 0.0), lin.weight, lin.bias, None)      # shared weight
+        z = C.conv_transpose2x2(C.bn_relu(C.conv2d(img, conv.weight, conv.bias, 1), bn), up.weight, up.bias)
+        return (y * y).sum() + (z * z).sum()
+
+    def theirs():
+        lw, lb, cw, cb, g, b, uw, ub = ref
+        F = torch.nn.functional
+        y = F.linear(F.relu(F.linear(x.double(), lw, lb)), lw, lb)
+        z = F.conv2d(img.double(), cw, cb, padding=1)
+        z = F.relu(F.batch_norm(z, None, None, g, b, training=True, eps=bn.eps))
+        z = F.conv_transpose2d(z, uw, ub, stride=2)
+        return (y * y).sum() + (z * z).sum()
+
+    opt.zero_grad()
+    loss = mine()
+    loss.backward(retain_graph=True)
+    loss.backward()                                   # accumulates on top of the first
+    lr = theirs()
+    lr.backward(retain_graph=True)
+    lr.backward()
+    def check(scale):
+        for p, r in zip(params, ref):
+            if float(r.grad.abs().max()) < 1e-9:          # conv bias in front of BatchNorm: exactly zero in theory
+                assert float(p.grad.abs().max()) < 1e-3
+            else:
+                close(p.grad, scale * r.grad.float(), 2e-5, 'sink grad')
+
+    check(1.0)
+    opt.zero_grad()                                   # a new step stores again (no stale accumulation)
+    mine().backward()
+    check(0.5)
+
+
 @pytest.mark.parametrize('B', [1, 3])
 def test_sweep_entry_equals_dropin(dev, B):
     """PathModel.forward_sweep (whole-sweep entry) vs the per-level drop-in loop: same predictions and
