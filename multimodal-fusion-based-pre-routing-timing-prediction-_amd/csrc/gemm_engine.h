@@ -20,6 +20,11 @@
 #pragma once
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
+
+#ifndef MMFT_GEMM_PF
+#define MMFT_GEMM_PF 1
+#endif
 
 namespace mmft {
 
@@ -28,6 +33,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int BM_, int BN_, int BK_, int WM_, int WN_>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
+  static constexpr int PF = MMFT_GEMM_PF;      // register prefetch depth (k-steps in flight)
   static_assert(WM_ * WN_ == 4, "4 waves per workgroup");
   static_assert(BM_ % (16 * WM_) == 0 && BN_ % (16 * WN_) == 0, "tile/wave mismatch");
 };
@@ -67,6 +73,11 @@ struct DenseMK {
     if (k + 3 < kend) v.w = c.row[k + 3];
     return v;
   }
+  // interior tiles (all rows valid, 16-byte loads legal, whole K step inside the range): no per-load guards
+  __device__ __forceinline__ bool interior(int m0, int bm) const { return vec && m0 + bm <= rows; }
+  __device__ __forceinline__ f32x4 load_fast(const Ctx& c, int k) const {
+    return *reinterpret_cast<const f32x4*>(c.row + k);
+  }
 };
 
 struct DenseKM {
@@ -92,6 +103,11 @@ struct DenseKM {
     if (c.m + 2 < cols) v.z = q[2];
     if (c.m + 3 < cols) v.w = q[3];
     return v;
+  }
+  __device__ __forceinline__ bool interior(int m0, int bm) const { return vec && m0 + bm <= cols; }
+  __device__ __forceinline__ f32x4 load_fast(const Ctx& c, int k) const {
+    long long r = kidx ? (long long)kidx[k] : (long long)k;
+    return *reinterpret_cast<const f32x4*>(p + r * ld + c.m);
   }
 };
 
@@ -328,6 +344,22 @@ struct Epi {
 };
 
 // ------------------------------------------------------------------------------------ kernel
+// loaders that offer an unguarded path for interior tiles (interior() + load_fast()); the others keep load()
+template <class L, class = void>
+struct has_fast : std::false_type {};
+template <class L>
+struct has_fast<L, std::void_t<decltype(&L::load_fast)>> : std::true_type {};
+template <class L>
+__device__ __forceinline__ bool fast_interior(const L& l, int m0, int bm) {
+  if constexpr (has_fast<L>::value) return l.interior(m0, bm);
+  else return false;
+}
+template <class L, class C>
+__device__ __forceinline__ f32x4 fast_load(const L& l, const C& c, int k, int kend) {
+  if constexpr (has_fast<L>::value) return l.load_fast(c, k);
+  else return l.load(c, k, kend);
+}
+
 template <bool KMAJOR, int S>
 __device__ __forceinline__ void read_frag(const float* tile, int row0, int kb, int lane, float (&f)[4]) {
   if (!KMAJOR) {
@@ -403,34 +435,47 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(XL xl, WL wl, Epi epi, in
 #pragma unroll
   for (int a = 0; a < RT; ++a) cs[a] = 0.f;
 
-  f32x4 xr[XN], wr[WNL];
-  auto gload = [&](int k0) {
+  // global -> register -> LDS pipeline.  PF register sets: with PF = 2 the loads of tile t+2 are issued while tile t is
+  // multiplied and tile t+1 waits in the other set, so a load has two k-steps (~1.7 us at BK = 16) to come back from
+  // HBM instead of one; the set index is a compile-time constant so that the arrays stay in registers.
+  constexpr int PF = CFG::PF;
+  f32x4 xr[PF][XN], wr[PF][WNL];
+  const bool x_in = has_fast<XL>::value && fast_interior(xl, m0, BM);     // block-uniform
+  const bool w_in = has_fast<WL>::value && fast_interior(wl, n0, BN);
+  auto gload = [&](auto set, int k0) {
+    constexpr int S = decltype(set)::value;
+    const bool whole = k0 + BK <= kend;
+    if (x_in && whole) {
 #pragma unroll
-    for (int i = 0; i < XN; ++i)
-      if (XG % 256 == 0 || tid + i * 256 < XG) xr[i] = xl.load(xc[i], k0 + xk[i], kend);
+      for (int i = 0; i < XN; ++i)
+        if (XG % 256 == 0 || tid + i * 256 < XG) xr[S][i] = fast_load(xl, xc[i], k0 + xk[i], kend);
+    } else {
 #pragma unroll
-    for (int i = 0; i < WNL; ++i)
-      if (WG % 256 == 0 || tid + i * 256 < WG) wr[i] = wl.load(wc[i], k0 + wk[i], kend);
+      for (int i = 0; i < XN; ++i)
+        if (XG % 256 == 0 || tid + i * 256 < XG) xr[S][i] = xl.load(xc[i], k0 + xk[i], kend);
+    }
+    if (w_in && whole) {
+#pragma unroll
+      for (int i = 0; i < WNL; ++i)
+        if (WG % 256 == 0 || tid + i * 256 < WG) wr[S][i] = fast_load(wl, wc[i], k0 + wk[i], kend);
+    } else {
+#pragma unroll
+      for (int i = 0; i < WNL; ++i)
+        if (WG % 256 == 0 || tid + i * 256 < WG) wr[S][i] = wl.load(wc[i], k0 + wk[i], kend);
+    }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](auto set, int buf) {
+    constexpr int S = decltype(set)::value;
     float* xs = lds + buf * (XSZ + WSZ);
     float* ws = xs + XSZ;
 #pragma unroll
     for (int i = 0; i < XN; ++i)
-      if (XG % 256 == 0 || tid + i * 256 < XG) *reinterpret_cast<f32x4*>(xs + xo[i]) = xr[i];
+      if (XG % 256 == 0 || tid + i * 256 < XG) *reinterpret_cast<f32x4*>(xs + xo[i]) = xr[S][i];
 #pragma unroll
     for (int i = 0; i < WNL; ++i)
-      if (WG % 256 == 0 || tid + i * 256 < WG) *reinterpret_cast<f32x4*>(ws + wo[i]) = wr[i];
+      if (WG % 256 == 0 || tid + i * 256 < WG) *reinterpret_cast<f32x4*>(ws + wo[i]) = wr[S][i];
   };
-
-  if (nk > 0) {
-    gload(kbeg);
-    lstore(0);
-  }
-  __syncthreads();
-  int buf = 0;
-  for (int t = 0; t < nk; ++t) {
-    if (t + 1 < nk) gload(kbeg + (t + 1) * BK);
+  auto multiply = [&](int buf) {
     const float* xs = lds + buf * (XSZ + WSZ);
     const float* ws = xs + XSZ;
 #pragma unroll
@@ -452,9 +497,42 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(XL xl, WL wl, Epi epi, in
           for (int b = 0; b < FT; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[b][s], xf[a][s], acc[a][b], 0, 0, 0);
     }
-    if (t + 1 < nk) lstore(buf ^ 1);
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, PF - 1>;
+
+  if (PF == 1) {
+    if (nk > 0) {
+      gload(S0{}, kbeg);
+      lstore(S0{}, 0);
+    }
     __syncthreads();
-    buf ^= 1;
+    int buf = 0;
+    for (int t = 0; t < nk; ++t) {
+      if (t + 1 < nk) gload(S0{}, kbeg + (t + 1) * BK);
+      multiply(buf);
+      if (t + 1 < nk) lstore(S0{}, buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  } else {
+    if (nk > 0) gload(S0{}, kbeg);
+    if (nk > 1) gload(S1{}, kbeg + BK);
+    if (nk > 0) lstore(S0{}, 0);
+    __syncthreads();
+    // even step t: set 0 is free (tile t sits in LDS), set 1 holds tile t+1; odd steps mirror that
+    for (int t = 0; t < nk; t += 2) {
+      if (t + 2 < nk) gload(S0{}, kbeg + (t + 2) * BK);
+      multiply(0);
+      if (t + 1 < nk) lstore(S1{}, 1);
+      __syncthreads();
+      if (t + 1 < nk) {
+        if (t + 3 < nk) gload(S1{}, kbeg + (t + 3) * BK);
+        multiply(1);
+        if (t + 2 < nk) lstore(S0{}, 0);
+        __syncthreads();
+      }
+    }
   }
 
 #pragma unroll

@@ -28,7 +28,7 @@ def run(tag, M, N, K, **kw):
     print(f'{tag:40s} M={M:7d} N={N:4d} K={K:5d}  {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF', flush=True)
 
 
-if __name__ == '__main__':
+if __name__ == "__main__":
     run('fwd MK,MK plain', 245760, 256, 128)
     run('fwd MK,MK plain', 245760, 128, 256)
     run('fwd MK,MK plain', 245760, 256, 36)
