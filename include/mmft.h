@@ -70,6 +70,17 @@ long long mmft_linear_wgrad_bias_workspace_bytes(int rows, int out, int in);
 int mmft_linear_wgrad_bias(const float* g, const int* gidx, long long ldg, const float* x, const int* xidx,
                            long long ldx, float* dw, long long lddw, float* db, int rows, int out, int in,
                            int accumulate, float* workspace, long long workspace_bytes, int device, void* stream);
+/* Gradients of the FIRST Linear of a Linear-ReLU-Linear MLP (reference MLP(in, 256, out), src/model.py:10-24; the
+ * fc_cell_self / fc_net_self instances of PathConv, src/model.py:66-67) straight from the gradient of the MLP's
+ * output, without materialising the hidden gradient:
+ *   dH = (g[r] . w2) * (hid[r] > 0);  dw1[HD][fin] (+)= dH^T . x[r];  db1[HD] (+)= column sums of dH
+ * over the rows r = rows ? rows[i] : row0 + i, i < n, of the node-indexed buffers g [*, D2], hid [*, HD], x [*, fin];
+ * w2 is the second layer's weight [D2][HD].  fin <= 48, HD = 256, D2 = 128 (else MMFT_ERR_UNSUPPORTED). */
+long long mmft_mlp2_first_layer_grads_workspace_bytes(int fin, int HD);
+int mmft_mlp2_first_layer_grads(const float* g, long long ldg, const float* hid, long long ldh, const float* x,
+                                long long ldx, const int* rows, int row0, int n, const float* w2, long long ldw2,
+                                float* dw1, float* db1, int fin, int HD, int D2, int accumulate, float* workspace,
+                                long long workspace_bytes, int device, void* stream);
 /* Fused Linear-ReLU-Linear over gathered rows, hidden tile kept in LDS (one launch per cell level of the sweep;
  * PathConv.apply_cell_func's fc_cell_neigh, src/model.py:138-146, and its backward):
  *   hid = mask ? (x1[rows] . W1) * (mask[rows] > 0) : relu(x1[rows] . W1 + b1)

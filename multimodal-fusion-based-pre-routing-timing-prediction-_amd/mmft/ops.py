@@ -139,6 +139,31 @@ def linear_wgrad(g, x, dw=None, gidx=None, xidx=None, rows=None, accumulate=Fals
     return dw
 
 
+def first_layer_grads_fusable(fin, HD, D2):
+    return fin <= 48 and HD == 256 and D2 == 128
+
+
+def mlp2_first_layer_grads(g, hid, x, rows, w2, dw1=None, db1=None):
+    """(dW1, db1) of a Linear-ReLU-Linear MLP from the gradient g of its output, over the node rows `rows`
+    (int32 tensor | (start, n) | None = all): dH = (g w2) * (hid > 0) stays in registers (mmft_mlp2_first_layer_grads)."""
+    _rows2d(g, 'g'); _rows2d(hid, 'hid'); _rows2d(x, 'x'); _rows2d(w2, 'w2')
+    D2, HD = w2.shape
+    fin = x.shape[1]
+    if g.shape[1] != D2 or hid.shape[1] != HD or g.shape[0] != hid.shape[0] or g.shape[0] != x.shape[0]:
+        raise ValueError('mlp2_first_layer_grads: shapes')
+    idx, row0, n = _rowspec(rows, g.shape[0], 'rows')
+    dw1 = torch.empty((HD, fin), dtype=torch.float32, device=g.device) if dw1 is None else dw1
+    db1 = torch.empty(HD, dtype=torch.float32, device=g.device) if db1 is None else db1
+    _chk(dw1, 'dw1'); _chk(db1, 'db1')
+    if tuple(dw1.shape) != (HD, fin) or not dw1.is_contiguous() or db1.numel() != HD or not db1.is_contiguous():
+        raise ValueError('mlp2_first_layer_grads: output shapes')
+    ws = lib.workspace(g.device, lib.query('mmft_mlp2_first_layer_grads_workspace_bytes', fin, HD))
+    dev, st = lib.stream_args(g)
+    lib.call('mmft_mlp2_first_layer_grads', g, g.stride(0), hid, hid.stride(0), x, x.stride(0), idx, row0, n, w2,
+             w2.stride(0), dw1, db1, fin, HD, D2, 0, ws, ws.numel() * 4, dev, st)
+    return dw1, db1
+
+
 def mlp2_fusable(K1, HD, D2):
     return (K1, HD, D2) == (128, 256, 128)
 

@@ -191,6 +191,11 @@ def _mlp_grads(st, sinks, G, gidx, H, X, xidx, w2, dH_rows=None):
     if dH_rows is not None:
         dW1, db1 = gradsink.deliver_pair(s1w, s1b, lambda ow, ob: ops.linear_wgrad(dH_rows, X, dw=ow, gidx=gidx,
                                                                                    xidx=xidx, db=ob, with_bias=True))
+    elif FUSED_FIRST_LAYER_GRADS and xidx is gidx and ops.first_layer_grads_fusable(X.shape[1], H.shape[1], G.shape[1]) \
+            and w2.stride(0) % 4 == 0:
+        # dH = (G W2) * relu'(H) never leaves the registers: one launch instead of GEMM -> 268 MB -> GEMM
+        dW1, db1 = gradsink.deliver_pair(s1w, s1b, lambda ow, ob: ops.mlp2_first_layer_grads(G, H, X, gidx, w2, dw1=ow,
+                                                                                             db1=ob))
     else:
         dH = ops.linear_dgrad(G, w2, gidx=gidx, mask=H, maskidx=gidx)
         dW1, db1 = gradsink.deliver_pair(s1w, s1b, lambda ow, ob: ops.linear_wgrad(dH, X, dw=ow, xidx=xidx, db=ob,
@@ -258,6 +263,7 @@ def level_forward(conv, graph, cur_nodes, targets, level_id):
 # wave per SIMD either way, and the software barrier over 252 workgroups (arrival skew of the slowest tile included)
 # costs more than the ~2 us hardware kernel boundary it replaces.  Off by default.
 PERSISTENT_FORWARD = False
+FUSED_FIRST_LAYER_GRADS = True      # mmft_mlp2_first_layer_grads for the *_self MLPs (False: dgrad GEMM + wgrad GEMM)
 
 
 def _persist_state(graph, level_rows):

@@ -81,6 +81,31 @@ def test_linear_wgrad_colsum(dev, rows, out, inn):
     assert torch.equal(ops.linear_wgrad(g, x, with_bias=True)[1], db3)
 
 
+@pytest.mark.parametrize('fin,n,mode', [(36, 5000, 'idx'), (2, 4099, 'range'), (48, 37, 'idx'), (17, 16, 'all'),
+                                        (36, 70001, 'range'), (4, 3, 'idx')])
+def test_mlp2_first_layer_grads(dev, fin, n, mode):
+    """Fused (dW1, db1) of a Linear-ReLU-Linear MLP vs fp64 torch: dH = (G W2) * (H > 0) is never stored."""
+    NN, HD, D2 = n + 300, 256, 128
+    g, hid, x = T((NN, D2), 1, dev), T((NN, HD), 2, dev), T((NN, fin), 3, dev)
+    w2 = T((D2, HD), 4, dev)
+    if mode == 'idx':
+        rows = torch.randperm(NN)[:n].to(torch.int32).to(dev)
+        sel = rows.long()
+    elif mode == 'range':
+        rows = (123, n)
+        sel = torch.arange(123, 123 + n, device=dev)
+    else:
+        NN = n
+        g, hid, x = g[:n].contiguous(), hid[:n].contiguous(), x[:n].contiguous()
+        rows, sel = None, torch.arange(n, device=dev)
+    dH = (g.double()[sel] @ w2.double()) * (hid.double()[sel] > 0)
+    ref_w, ref_b = dH.t() @ x.double()[sel], dH.sum(0)
+    dw1, db1 = ops.mlp2_first_layer_grads(g, hid, x, rows, w2)
+    assert rel_err(dw1, ref_w) < TOL and rel_err(db1, ref_b) < TOL
+    dw1b, db1b = ops.mlp2_first_layer_grads(g, hid, x, rows, w2)
+    assert torch.equal(dw1, dw1b) and torch.equal(db1, db1b)          # fixed reduction order
+
+
 def test_linear_wgrad_indexed(dev):
     R_, rows, out, inn = 5000, 3000, 128, 36
     g, x = T((R_, out), 1, dev), T((R_, inn), 2, dev)
