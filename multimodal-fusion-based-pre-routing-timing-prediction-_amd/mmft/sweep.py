@@ -175,10 +175,30 @@ class LevelFn(torch.autograd.Function):
 
 
 def _cat_rows(st, pred):
-    sel = [r for (l, r) in st.levels if pred(l) and r.numel()]
+    """Rows of the levels selected by `pred`, in level order: a (start, n) range when the levels are contiguous id
+    ranges that follow each other (DesignBatch's renumbering makes them so), else one int32 index tensor."""
+    sel = [(l, r) for (l, r) in st.levels if pred(l) and r.numel()]
     if not sel:
         return None
-    return sel[0] if len(sel) == 1 else torch.cat(sel)
+    if st.level_meta:
+        rng = [st.level_meta[l]['range'] if st.level_meta[l] else None for l, _ in sel]
+        if all(rng) and all(rng[i][0] + rng[i][1] == rng[i + 1][0] for i in range(len(rng) - 1)):
+            return (rng[0][0], sum(n for _, n in rng))
+    return sel[0][1] if len(sel) == 1 else torch.cat([r for _, r in sel])
+
+
+def _rows_of(t, rows):
+    """(tensor the kernel should see, index tensor or None) for a row set that is a range or an index tensor."""
+    if isinstance(rows, tuple):
+        return t[rows[0]:rows[0] + rows[1]], None
+    return t, rows
+
+
+def _linear_rows(x, w, b, y, rows, **kw):
+    """y[rows] = epi(x[rows] @ w.T + b) for a range or an index row set."""
+    xv, idx = _rows_of(x, rows)
+    yv, _ = _rows_of(y, rows)
+    return ops.linear_fwd(xv, w, b, y=yv, xidx=idx, yidx=idx, **kw)
 
 
 def _mlp_grads(st, sinks, G, gidx, H, X, xidx, w2, dH_rows=None):
@@ -186,19 +206,23 @@ def _mlp_grads(st, sinks, G, gidx, H, X, xidx, w2, dH_rows=None):
     has a gradient sink (mmft.gradsink) are written there and returned as None.
     dH_rows: [N, Hd] buffer already holding the hidden gradients of those rows (from the level loop)."""
     s1w, s1b, s2w, s2b = sinks
-    dW2, db2 = gradsink.deliver_pair(s2w, s2b, lambda ow, ob: ops.linear_wgrad(G, H, dw=ow, gidx=gidx, xidx=gidx, db=ob,
+    Gv, gi = _rows_of(G, gidx)
+    Hv, _ = _rows_of(H, gidx)
+    Xv, xi = _rows_of(X, xidx)
+    dW2, db2 = gradsink.deliver_pair(s2w, s2b, lambda ow, ob: ops.linear_wgrad(Gv, Hv, dw=ow, gidx=gi, xidx=gi, db=ob,
                                                                                with_bias=True))
     if dH_rows is not None:
-        dW1, db1 = gradsink.deliver_pair(s1w, s1b, lambda ow, ob: ops.linear_wgrad(dH_rows, X, dw=ow, gidx=gidx,
-                                                                                   xidx=xidx, db=ob, with_bias=True))
+        Dv, _ = _rows_of(dH_rows, gidx)
+        dW1, db1 = gradsink.deliver_pair(s1w, s1b, lambda ow, ob: ops.linear_wgrad(Dv, Xv, dw=ow, gidx=gi, xidx=xi,
+                                                                                   db=ob, with_bias=True))
     elif FUSED_FIRST_LAYER_GRADS and xidx is gidx and ops.first_layer_grads_fusable(X.shape[1], H.shape[1], G.shape[1]) \
             and w2.stride(0) % 4 == 0:
         # dH = (G W2) * relu'(H) never leaves the registers: one launch instead of GEMM -> 268 MB -> GEMM
         dW1, db1 = gradsink.deliver_pair(s1w, s1b, lambda ow, ob: ops.mlp2_first_layer_grads(G, H, X, gidx, w2, dw1=ow,
                                                                                              db1=ob))
     else:
-        dH = ops.linear_dgrad(G, w2, gidx=gidx, mask=H, maskidx=gidx)
-        dW1, db1 = gradsink.deliver_pair(s1w, s1b, lambda ow, ob: ops.linear_wgrad(dH, X, dw=ow, xidx=xidx, db=ob,
+        dH = ops.linear_dgrad(Gv, w2, gidx=gi, mask=Hv, maskidx=gi)
+        dW1, db1 = gradsink.deliver_pair(s1w, s1b, lambda ow, ob: ops.linear_wgrad(dH, Xv, dw=ow, xidx=xi, db=ob,
                                                                                    with_bias=True))
     return [dW1, db1, dW2, db2]
 
@@ -303,14 +327,15 @@ class SweepFn(torch.autograd.Function):
         rn = _cat_rows(st, lambda l: l % 2 == 1)
         st.row_sets = (_cat_rows(st, lambda l: l % 2 == 0), rn, rc2)
         if r0.numel():                                                                   # level 0, :148-153
-            ops.linear_fwd(st.cell_feat, w1c, b1c, y=st.HS, xidx=r0, yidx=r0, act=ops.ACT_RELU)
-            ops.linear_fwd(st.HS, w2c, b2c, y=st.h, xidx=r0, yidx=r0, act=act)
+            r0s = _cat_rows(st, lambda l: l == 0)
+            _linear_rows(st.cell_feat, w1c, b1c, st.HS, r0s, act=ops.ACT_RELU)
+            _linear_rows(st.HS, w2c, b2c, st.h, r0s, act=act)
         if rc2 is not None:                                                              # fc_cell_self, all cell nodes
-            ops.linear_fwd(st.cell_feat, w1c, b1c, y=st.HS, xidx=rc2, yidx=rc2, act=ops.ACT_RELU)
-            ops.linear_fwd(st.HS, w2c, b2c, y=st.h, xidx=rc2, yidx=rc2)
+            _linear_rows(st.cell_feat, w1c, b1c, st.HS, rc2, act=ops.ACT_RELU)
+            _linear_rows(st.HS, w2c, b2c, st.h, rc2)
         if rn is not None:                                                               # fc_net_self, all net nodes
-            ops.linear_fwd(st.net_feat, w1n, b1n, y=st.HS, xidx=rn, yidx=rn, act=ops.ACT_RELU)
-            ops.linear_fwd(st.HS, w2n, b2n, y=st.h, xidx=rn, yidx=rn)
+            _linear_rows(st.net_feat, w1n, b1n, st.HS, rn, act=ops.ACT_RELU)
+            _linear_rows(st.HS, w2n, b2n, st.h, rn)
         in_net, in_cell = g.csr('in', 'net'), g.csr('in', 'cell')
         persistent = PERSISTENT_FORWARD and ops.mlp2_fusable(st.D, st.Hd, st.D) and len(level_rows) > 1
         if persistent:

@@ -49,10 +49,11 @@ class DesignBatch:
     """B designs resident on the device, merged block-diagonally."""
 
     def __init__(self, designs, device, out_dim=128, renumber=True):
-        """renumber: give the merged nodes level-major ids (level 0 of every design first, then level 1, ...), so that
-        every level is one contiguous id range: the level's own rows of h / G / A stream through memory and the
-        gathered neighbour rows of adjacent levels sit next to each other.  Purely internal: ids handed back to the
-        caller are the original merged ids."""
+        """renumber: give the merged nodes level-major ids with the cell levels (0, 2, 4, ...) before the net levels
+        (1, 3, 5, ...).  Every level is then one contiguous id range (its rows of h / G / A stream through memory, no
+        index array), and so are the three row sets the batched GEMMs of the sweep run over - all cell levels, the
+        cell levels after level 0, all net levels - which therefore need no row gather / scatter either.  Purely
+        internal: ids handed back to the caller are the original merged ids."""
         self.designs = designs
         self.B = len(designs)
         self.device = torch.device(device)
@@ -65,7 +66,7 @@ class DesignBatch:
             parts = [d.levels[l] + self.node_off[i] for i, d in enumerate(designs) if l < d.L]
             levels_old.append(np.concatenate(parts))
         if renumber:
-            order = np.concatenate(levels_old)                       # new id k <- old id order[k]
+            order = np.concatenate(levels_old[0::2] + levels_old[1::2])          # new id k <- old id order[k]
             rest = np.setdiff1d(np.arange(self.N), order)             # nodes in no level keep trailing ids
             order = np.concatenate([order, rest])
             new_of_old = np.empty(self.N, dtype=np.int64)

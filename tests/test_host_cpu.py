@@ -131,12 +131,13 @@ def test_design_batch_select_order():
     assert counts.sum() == 6 and len(b.level_nodes) == 8
     first, nxt = b.links
     assert first.numel() == b.path_off[-1] and nxt.numel() == 6
-    # level-major renumbering is internal: every level becomes one contiguous id range, ids handed back are unchanged
+    # the renumbering is internal: ids handed back are unchanged
     r = DesignBatch(ds, 'cpu', renumber=True)
     ends_r, _, _, _, ends_h_r, _ = r.select(ids)
     assert ends_h_r.tolist() == ends_h.tolist() and r.old_of_new[ends_r.numpy()].tolist() == ends_h.tolist()
+    # cell levels (0, 2, ...) first, then net levels (1, 3, ...): every level AND the cell / net row sets are ranges
     start = 0
-    for lv_nodes in r.level_nodes:
+    for lv_nodes in r.level_nodes[0::2] + r.level_nodes[1::2]:
         assert lv_nodes == list(range(start, start + len(lv_nodes)))
         start += len(lv_nodes)
     assert torch.equal(r.graph.ndata['cell_feat'], b.graph.ndata['cell_feat'][torch.from_numpy(r.old_of_new)])
