@@ -259,6 +259,36 @@ int mmft_adam_step_dev(float* p, const float* g, float* m, float* v, long long n
                        float beta1, float beta2, float eps, float weight_decay, float gscale,
                        int device, void* stream);
 
+/* ---- design preprocessing: the graph-side steps the reference runs on networkx in Python ---- */
+/* Longest-path levels from the primary inputs `pis` (src/verilog_parser_asap7.py:1452-1517, cal_topo_level: frontier
+ * expansion + reverse de-duplication = every node keeps the LAST level it appears in).  Up to two out-edge CSRs
+ * (net, cell; second may be NULL).  level[v] = -1 for nodes no PI reaches; *num_levels is a HOST int.  Synchronises
+ * the stream between chunks of steps (preprocessing, not the training step). */
+long long mmft_levelize_workspace_bytes(int n);
+int mmft_levelize(const int* out_indptr0, const int* out_indices0, const int* out_indptr1, const int* out_indices1,
+                  int n, const int* pis, int npi, int* level, int* num_levels, void* workspace,
+                  long long workspace_bytes, int device, void* stream);
+/* One critical path per endpoint (src/verilog_parser_asap7.py:1433-1450, find_critical_path): walk back while the
+ * level is >= 2, each time to the FIRST in-neighbour (CSR 0 then CSR 1, insertion order) exactly one level below;
+ * an in-neighbour flagged in `stop` (the reference's 'clk' name test; may be NULL) met first ends the walk.
+ * paths[npaths][maxlen] padded with -1; lens[i] > maxlen means row i was truncated. */
+int mmft_trace_critical_paths(const int* in_indptr0, const int* in_indices0, const int* in_indptr1,
+                              const int* in_indices1, const int* level, const unsigned char* stop,
+                              const int* endpoints, int npaths, int maxlen, int* paths, int* lens, int device,
+                              void* stream);
+/* Path masks (src/verilog_parser_asap7.py:1302-1369, masking == 'critical'): row i = union over consecutive pins of
+ * path i of the bounding box of their map locations, column = x * map_y + y, as CSR with ascending columns.
+ * Two passes: count (-> counts[npaths]; the caller scans them into indptr), then fill. */
+int mmft_path_mask_count(const int* paths, const int* lens, int npaths, int maxlen, const int* loc_x, const int* loc_y,
+                         int map_x, int map_y, int* counts, int device, void* stream);
+int mmft_path_mask_fill(const int* paths, const int* lens, int npaths, int maxlen, const int* loc_x, const int* loc_y,
+                        int map_x, int map_y, const int* indptr, int* cols, int device, void* stream);
+/* In-place per-column min-max scaling of columns [start_col, C) (src/train.py:309-318): (a - min) / (max - min),
+ * same two roundings; NaN where max == min or the column holds a NaN, as torch. */
+long long mmft_minmax_workspace_bytes(int n, int ncol);
+int mmft_minmax_normalize(float* feat, long long ld, int n, int C, int start_col, float* workspace,
+                          long long workspace_bytes, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

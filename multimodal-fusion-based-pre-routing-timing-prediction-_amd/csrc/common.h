@@ -63,17 +63,19 @@ struct ProfScope {
 // 8-20 us kernels are not inflated by launch gaps.
 void prof_events(const char* name, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1);
 void prof_commit();
-#define MMFT_LAUNCH(name, flops, bytes, kernel, grid, block, st, ...)                                        \
+#define MMFT_LAUNCH_LDS(name, flops, bytes, kernel, grid, block, lds, st, ...)                               \
   do {                                                                                                       \
     if (mmft::prof_on()) {                                                                                   \
       hipEvent_t mmft_e0_, mmft_e1_;                                                                         \
       mmft::prof_events(name, flops, bytes, &mmft_e0_, &mmft_e1_);                                           \
-      hipExtLaunchKernelGGL(kernel, grid, block, 0, st, mmft_e0_, mmft_e1_, 0, __VA_ARGS__);                 \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, st, mmft_e0_, mmft_e1_, 0, __VA_ARGS__);               \
       mmft::prof_commit();                                                                                   \
     } else {                                                                                                 \
-      hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                                           \
+      hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                         \
     }                                                                                                        \
   } while (0)
+#define MMFT_LAUNCH(name, flops, bytes, kernel, grid, block, st, ...) \
+  MMFT_LAUNCH_LDS(name, flops, bytes, kernel, grid, block, 0, st, __VA_ARGS__)
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -94,11 +94,14 @@ __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
     int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
     int v = rows ? rows[i] : row0 + i;
     long long off = (long long)v * ld + c;
+    // both edge ranges are requested up front: a node has net OR cell consumers, and the second pointer pair would
+    // otherwise start its own dependent chain (pointer -> index -> row) only after the first loop
+    int e = on_ptr[v], e1 = on_ptr[v + 1];
+    const int c0 = oc_ptr[v], c1 = oc_ptr[v + 1];
     f32x4 hv = ld4(h + off);
     f32x4 g = ld4(G + off);
     // net consumers: d/dh[v] of the mean over the consumer's in-edges (weight = 1/indeg, per out-edge, static).
     // Four edges are issued together so that the dependent index -> row loads of different edges overlap.
-    int e = on_ptr[v], e1 = on_ptr[v + 1];
     for (; e + 4 <= e1; e += 4) {
       int w0 = on_idx[e], w1 = on_idx[e + 1], w2 = on_idx[e + 2], w3 = on_idx[e + 3];
       float s0 = on_w[e], s1 = on_w[e + 1], s2 = on_w[e + 2], s3 = on_w[e + 3];
@@ -111,8 +114,8 @@ __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
     }
     for (; e < e1; ++e) g += ld4(G + (long long)on_idx[e] * ld + c) * on_w[e];
     // cell consumers: d a_c / d m_jc = w_jc (1 + m_jc - a_c),  w_jc = exp(m_jc - LSE_c)
-    e = oc_ptr[v];
-    e1 = oc_ptr[v + 1];
+    e = c0;
+    e1 = c1;
     for (; e + 2 <= e1; e += 2) {
       long long o0 = (long long)oc_idx[e] * ld + c, o1 = (long long)oc_idx[e + 1] * ld + c;
       f32x4 da0 = ld4(DA + o0), a0 = ld4(A + o0), l0 = ld4(LSE + o0);

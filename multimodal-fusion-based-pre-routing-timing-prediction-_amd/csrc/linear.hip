@@ -103,11 +103,13 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
 }
 
 int launch_slab_reduce(const float* slabs, int splits, long long elems, float* out, int accumulate, hipStream_t st) {
-  ProfScope ps("slab_reduce_kernel", 0.0, 4.0 * (splits + 1.0) * elems, st);
+  const double by = 4.0 * (splits + 1.0) * elems;
   if (elems % 4 == 0 && aligned16(slabs)) {
-    hipLaunchKernelGGL(slab_reduce_kernel<4>, dim3(cdiv(elems, 64)), dim3(256), 0, st, slabs, splits, elems, out, accumulate);
+    MMFT_LAUNCH("slab_reduce_kernel", 0.0, by, slab_reduce_kernel<4>, dim3(cdiv(elems, 64)), dim3(256), st, slabs, splits,
+                elems, out, accumulate);
   } else {
-    hipLaunchKernelGGL(slab_reduce_kernel<1>, dim3(cdiv(elems, 16)), dim3(256), 0, st, slabs, splits, elems, out, accumulate);
+    MMFT_LAUNCH("slab_reduce_kernel", 0.0, by, slab_reduce_kernel<1>, dim3(cdiv(elems, 16)), dim3(256), st, slabs, splits,
+                elems, out, accumulate);
   }
   return check_launch("slab_reduce");
 }
@@ -357,10 +359,8 @@ int mmft_colsum(const float* g, const int* idx, long long ld, int rows, int cols
   }
   int nb = colsum_blocks(rows);
   MMFT_REQUIRE(workspace && workspace_bytes >= (long long)nb * cols * 4, "colsum: workspace too small");
-  {
-    ProfScope ps("colsum_partial_kernel", 0.0, 4.0 * rows * cols, st);   // scoped: slab_reduce below has its own
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(cols, 64), nb), dim3(256), 0, st, g, idx, ld, rows, cols, workspace);
-  }
+  MMFT_LAUNCH("colsum_partial_kernel", 0.0, 4.0 * rows * cols, colsum_partial_kernel, dim3(cdiv(cols, 64), nb), dim3(256), st,
+              g, idx, ld, rows, cols, workspace);
   int rc = check_launch("colsum_partial");
   if (rc) return rc;
   return launch_slab_reduce(workspace, nb, cols, out, accumulate, st);

@@ -140,9 +140,10 @@ extern "C" int mmft_mlp2_rows(const float* x1, long long ldx1, const int* rows, 
   DeviceGuard dg(device);
   hipStream_t st = (hipStream_t)stream;
   Mlp2Args a{x1, ldx1, rows, n, w1, ldw1, b1, w2, ldw2, b2, mask, ldmask, hid_out, ldhid, out, ldout, add_act, relu_out};
-  ProfScope ps(weights_kmajor ? "mlp2_rows_kernel<KM>" : "mlp2_rows_kernel<MK>", 2.0 * n * ((double)K1 * HD + (double)HD * D2),
-               4.0 * n * ((double)K1 + 2.0 * HD + 2.0 * D2), st);
-  if (weights_kmajor) hipLaunchKernelGGL(mlp2_rows_kernel<true>, dim3(cdiv(n, M2_BM)), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(mlp2_rows_kernel<false>, dim3(cdiv(n, M2_BM)), dim3(256), 0, st, a);
+  const double fl = 2.0 * n * ((double)K1 * HD + (double)HD * D2), by = 4.0 * n * ((double)K1 + 2.0 * HD + 2.0 * D2);
+  if (weights_kmajor)
+    MMFT_LAUNCH("mlp2_rows_kernel<KM>", fl, by, mlp2_rows_kernel<true>, dim3(cdiv(n, M2_BM)), dim3(256), st, a);
+  else
+    MMFT_LAUNCH("mlp2_rows_kernel<MK>", fl, by, mlp2_rows_kernel<false>, dim3(cdiv(n, M2_BM)), dim3(256), st, a);
   return check_launch("mlp2_rows");
 }

@@ -240,19 +240,17 @@ extern "C" int mmft_mlp2_first_layer_grads(const float* g, long long ldg, const 
       attr_done[ft] = true;
     }
   };
-  {
-    ProfScope ps("mlp_first_layer_grads_kernel", 2.0 * n * ((double)D2 * HD + (double)HD * ft * 16),
-                 4.0 * n * ((double)D2 + HD + fin), st);
-    if (ft == 1) {
-      set_attr((const void*)mlp_first_layer_grads_kernel<1>);
-      hipLaunchKernelGGL(mlp_first_layer_grads_kernel<1>, dim3(grid), dim3(MG_WAVES * 64), lds, st, a);
-    } else if (ft == 2) {
-      set_attr((const void*)mlp_first_layer_grads_kernel<2>);
-      hipLaunchKernelGGL(mlp_first_layer_grads_kernel<2>, dim3(grid), dim3(MG_WAVES * 64), lds, st, a);
-    } else {
-      set_attr((const void*)mlp_first_layer_grads_kernel<3>);
-      hipLaunchKernelGGL(mlp_first_layer_grads_kernel<3>, dim3(grid), dim3(MG_WAVES * 64), lds, st, a);
-    }
+  const double fl = 2.0 * n * ((double)D2 * HD + (double)HD * ft * 16), by = 4.0 * n * ((double)D2 + HD + fin);
+  const dim3 gr(grid), bl(MG_WAVES * 64);
+  if (ft == 1) {
+    set_attr((const void*)mlp_first_layer_grads_kernel<1>);
+    MMFT_LAUNCH_LDS("mlp_first_layer_grads_kernel", fl, by, mlp_first_layer_grads_kernel<1>, gr, bl, lds, st, a);
+  } else if (ft == 2) {
+    set_attr((const void*)mlp_first_layer_grads_kernel<2>);
+    MMFT_LAUNCH_LDS("mlp_first_layer_grads_kernel", fl, by, mlp_first_layer_grads_kernel<2>, gr, bl, lds, st, a);
+  } else {
+    set_attr((const void*)mlp_first_layer_grads_kernel<3>);
+    MMFT_LAUNCH_LDS("mlp_first_layer_grads_kernel", fl, by, mlp_first_layer_grads_kernel<3>, gr, bl, lds, st, a);
   }
   int rc = check_launch("mlp2_first_layer_grads");
   if (rc) return rc;
