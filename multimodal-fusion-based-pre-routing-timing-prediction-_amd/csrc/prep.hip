@@ -136,9 +136,18 @@ __global__ void __launch_bounds__(256) path_mask_kernel(const int* __restrict__ 
     y2 = y2 >= map_y ? map_y - 1 : y2;
     int w = y2 - y1 + 1, hgt = x2 - x1 + 1;
     if (w <= 0 || hgt <= 0) continue;
-    for (int c = tid; c < w * hgt; c += 256) {
-      int idx = (x1 + c / w) * map_y + y1 + c % w;
-      atomicOr(&bits[idx >> 5], 1u << (idx & 31));
+    // a box row is the contiguous bit range [x * map_y + y1, x * map_y + y2]: OR whole-word masks instead of one
+    // LDS atomic per cell (boxes of long nets cover thousands of cells)
+    const int wpr = ((w + 30) >> 5) + 1;                      // words a row's range can touch
+    for (int c = tid; c < hgt * wpr; c += 256) {
+      int row = c / wpr, k = c - row * wpr;
+      int lo = (x1 + row) * map_y + y1, hi = lo + w - 1;      // inclusive bit range
+      int word = (lo >> 5) + k;
+      if (word > (hi >> 5)) continue;
+      int b0 = word == (lo >> 5) ? (lo & 31) : 0;
+      int b1 = word == (hi >> 5) ? (hi & 31) : 31;
+      unsigned mask = (b1 == 31 ? 0xffffffffu : ((1u << (b1 + 1)) - 1u)) & ~((1u << b0) - 1u);
+      atomicOr(&bits[word], mask);
     }
   }
   __syncthreads();
