@@ -575,8 +575,10 @@ template <class CFG, class XL, class WL>
 inline void launch_cfg(const XL& xl, const WL& wl, const Epi& epi, int M, int N, int K, int splits, hipStream_t st) {
   int ksplit = K;
   if (splits > 1) {
+    // 16-row granularity whatever BK is, so that the slab count equals effective_splits() (the callers size and sum
+    // the slabs with it); a K range that is not a multiple of BK ends in a guarded, zero-filled step
     int per = (K + splits - 1) / splits;
-    ksplit = ((per + CFG::BK - 1) / CFG::BK) * CFG::BK;
+    ksplit = ((per + 15) / 16) * 16;
     splits = (K + ksplit - 1) / ksplit;
   }
   dim3 grid(cdiv(M, CFG::BM), cdiv(N, CFG::BN), splits);
@@ -649,6 +651,29 @@ inline int launch_gemm(const XL& xl, const WL& wl, const Epi& epi, int M, int N,
       if (fbm == 128 && fbn == 64 && fbk == 16) { launch_cfg<TileCfg<128, 64, 16, 2, 2>>(xl, wl, epi, M, N, K, splits, st); return check_launch("gemm_f32"); }
       if (fbm == 64 && fbn == 128 && fbk == 16) { launch_cfg<TileCfg<64, 128, 16, 2, 2>>(xl, wl, epi, M, N, K, splits, st); return check_launch("gemm_f32"); }
       if (fbm == 64 && fbn == 64 && fbk == 16) { launch_cfg<TileCfg<64, 64, 16, 2, 2>>(xl, wl, epi, M, N, K, splits, st); return check_launch("gemm_f32"); }
+    }
+  }
+  // Split-K launches with a narrow tile (weight gradients of 16/32-channel convolutions: Co x 9Ci outputs over
+  // 524 288 pixels) have 8-16 MFMAs per wave and 16-deep K step: the K loop is a chain of global round trips.  A
+  // deeper K step makes 2-4x fewer of them with as many bytes in flight each.
+  if (splits > 1) {
+    static int deep = -1;                         // MMFT_GEMM_SPLITK_BK=16 switches the deep-K tiles off (tuning hook)
+    if (deep < 0) {
+      const char* e = getenv("MMFT_GEMM_SPLITK_BK");
+      deep = e ? atoi(e) : 64;
+    }
+    const int key = cand[pick][0] * 1000 + cand[pick][1];
+    if (deep >= 32) {
+      // measured at config B (us per launch, BK = 16 / 32 / 64): 64x32 scalar 119 / - / 66, 64x16 66 / - / 38,
+      // 16x128 118 / 109 / 138, 32x128 74 / 63 / -, 64x128 56 / 46 / -
+      if (key == 64016) { launch_cfg<TileCfg<64, 16, 64, 4, 1>>(xl, wl, epi, M, N, K, splits, st); return check_launch("gemm_f32"); }
+      if (key == 64032) { launch_cfg<TileCfg<64, 32, 64, 4, 1>>(xl, wl, epi, M, N, K, splits, st); return check_launch("gemm_f32"); }
+      if (key == 16128) { launch_cfg<TileCfg<16, 128, 32, 1, 4>>(xl, wl, epi, M, N, K, splits, st); return check_launch("gemm_f32"); }
+      if (key == 16064) { launch_cfg<TileCfg<16, 64, 32, 1, 4>>(xl, wl, epi, M, N, K, splits, st); return check_launch("gemm_f32"); }
+      if (key == 32128) { launch_cfg<TileCfg<32, 128, 32, 2, 2>>(xl, wl, epi, M, N, K, splits, st); return check_launch("gemm_f32"); }
+      if (key == 128032) { launch_cfg<TileCfg<128, 32, 32, 4, 1>>(xl, wl, epi, M, N, K, splits, st); return check_launch("gemm_f32"); }
+      if (key == 128016) { launch_cfg<TileCfg<128, 16, 32, 4, 1>>(xl, wl, epi, M, N, K, splits, st); return check_launch("gemm_f32"); }
+      if (key == 64128) { launch_cfg<TileCfg<64, 128, 32, 2, 2>>(xl, wl, epi, M, N, K, splits, st); return check_launch("gemm_f32"); }
     }
   }
 #define MMFT_GO(BM, BN, WM, WN) launch_cfg<TileCfg<BM, BN, 16, WM, WN>>(xl, wl, epi, M, N, K, splits, st)
