@@ -134,6 +134,7 @@ struct Im2colMK {
   int H, W, C, KH, KW, pad;
   int rows;  // Nimg*H*W
   ConvDecode dc;
+  double unique_bytes(double pixels) const { return 4.0 * pixels * C; }   // host side: the gathered NHWC tensor
   struct Ctx {
     int pix0, y, x;
   };
@@ -174,6 +175,7 @@ struct Im2colKM {
   int H, W, C, KH, KW, pad;
   int cols;  // KH*KW*C
   ConvDecode dc;
+  double unique_bytes(double pixels) const { return 4.0 * pixels * C; }   // host side: the gathered NHWC tensor
   struct Ctx {
     int dy, dx, ci;
   };
@@ -213,6 +215,7 @@ struct Im2colMKScalar {
   const float* p;
   int H, W, C, KH, KW, pad;
   int rows;
+  double unique_bytes(double pixels) const { return 4.0 * pixels * C; }
   typedef Im2colMK::Ctx Ctx;
   __device__ __forceinline__ Ctx ctx(int m) const {
     Im2colMK v{p, H, W, C, KH, KW, pad, rows, ConvDecode{-1, -1, -1, 0}};
@@ -240,6 +243,7 @@ struct Im2colKMScalar {
   const float* p;
   int H, W, C, KH, KW, pad;
   int cols;
+  double unique_bytes(double pixels) const { return 4.0 * pixels * C; }
   struct Ctx {
     int n;
   };
@@ -385,8 +389,18 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(XL xl, WL wl, Epi epi, in
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int kbeg = blockIdx.z * ksplit;
+  // XCD-aware tile order.  Workgroup ids go round-robin over the 8 XCDs (each with its own L2), so consecutive ids
+  // would put neighbouring tiles - which share halo rows in the implicit-GEMM loaders, X rows across N tiles and
+  // pixel rows across adjacent split-K ranges - on eight different L2s.  The launch is 1-D, padded to a multiple of
+  // 8 workgroups; id w takes position (w % 8) * (count / 8) + w / 8 of the (n fastest, then m, then k-split) order,
+  // so every XCD walks one contiguous eighth of the tiles.
+  const int gx = (M + BM - 1) / BM, gy = (N + BN - 1) / BN;
+  const int lin = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  const int ntile = lin % gy, mtile = (lin / gy) % gx, zsplit = lin / (gy * gx);
+  const int nsplit = (K > 0 && ksplit > 0) ? (K + ksplit - 1) / ksplit : 1;
+  if (zsplit >= nsplit) return;                                             // padding workgroups
+  const int m0 = mtile * BM, n0 = ntile * BN;
+  const int kbeg = zsplit * ksplit;
   const int kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
   const int nk = (kend - kbeg + BK - 1) / BK;
 
@@ -430,7 +444,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(XL xl, WL wl, Epi epi, in
 #pragma unroll
     for (int b = 0; b < FT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const bool do_cs = epi.colsum != nullptr && blockIdx.y == 0 && wn == 0;      // wave-uniform
+  const bool do_cs = epi.colsum != nullptr && ntile == 0 && wn == 0;      // wave-uniform
   float cs[RT];
 #pragma unroll
   for (int a = 0; a < RT; ++a) cs[a] = 0.f;
@@ -541,7 +555,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(XL xl, WL wl, Epi epi, in
     for (int b = 0; b < FT; ++b) {
       int m = m0 + (wm * RT + a) * 16 + (lane & 15);
       int n = n0 + (wn * FT + b) * 16 + (lane >> 4) * 4;
-      epi.store(m, n, acc[a][b], M, N, blockIdx.z);
+      epi.store(m, n, acc[a][b], M, N, zsplit);
     }
   if (do_cs) {
 #pragma unroll
@@ -551,7 +565,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(XL xl, WL wl, Epi epi, in
       v += __shfl_xor(v, 32, 64);
       int m = m0 + (wm * RT + a) * 16 + lane;
       if (lane < 16 && m < M) {
-        float* q = epi.colsum + (long long)blockIdx.z * epi.colsum_slab + m;
+        float* q = epi.colsum + (long long)zsplit * epi.colsum_slab + m;
         *q = (epi.colsum_accum ? *q : 0.f) + v;
       }
     }
@@ -571,6 +585,18 @@ inline const char* gemm_kernel_name() {
   return buf;
 }
 
+// algorithmic bytes of one operand: a dense operand is read once (rows x depth); an implicit-GEMM operand is the NHWC
+// tensor it gathers from (pixels x channels), not the KH*KW times larger virtual im2col matrix
+template <class L, class = void>
+struct has_unique_bytes : std::false_type {};
+template <class L>
+struct has_unique_bytes<L, std::void_t<decltype(&L::unique_bytes)>> : std::true_type {};
+template <class L>
+inline double operand_bytes(const L& l, double rows, double depth) {
+  if constexpr (has_unique_bytes<L>::value) return l.unique_bytes(L::KMAJOR ? depth : rows);
+  else return 4.0 * rows * depth;
+}
+
 template <class CFG, class XL, class WL>
 inline void launch_cfg(const XL& xl, const WL& wl, const Epi& epi, int M, int N, int K, int splits, hipStream_t st) {
   int ksplit = K;
@@ -581,9 +607,11 @@ inline void launch_cfg(const XL& xl, const WL& wl, const Epi& epi, int M, int N,
     ksplit = ((per + 15) / 16) * 16;
     splits = (K + ksplit - 1) / ksplit;
   }
-  dim3 grid(cdiv(M, CFG::BM), cdiv(N, CFG::BN), splits);
+  long long wgs = (long long)cdiv(M, CFG::BM) * cdiv(N, CFG::BN) * splits;
+  dim3 grid((unsigned)((wgs + 7) / 8 * 8));                                  // 1-D, padded: see the XCD-aware tile order
   // algorithmic work of this launch: 2*M*N*K flops; bytes = the three matrices touched once
-  MMFT_LAUNCH((gemm_kernel_name<CFG, XL, WL>()), 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), (gemm_f32_kernel<CFG, XL, WL>), grid, dim3(256), st, xl, wl, epi, M, N, K, ksplit);
+  const double alg_bytes = operand_bytes(xl, M, K) + operand_bytes(wl, N, K) + 4.0 * (double)M * N;
+  MMFT_LAUNCH((gemm_kernel_name<CFG, XL, WL>()), 2.0 * M * N * K, alg_bytes, (gemm_f32_kernel<CFG, XL, WL>), grid, dim3(256), st, xl, wl, epi, M, N, K, ksplit);
 }
 
 // number of split-K slabs launch_gemm will actually use for a requested count
