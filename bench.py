@@ -114,6 +114,8 @@ def main():
     ap.add_argument('--levels', type=int, default=64)
     ap.add_argument('--tile', type=int, default=256)
     ap.add_argument('--batch-paths', type=int, default=1350)
+    ap.add_argument('--fanin', default='regular', choices=['regular', 'irregular'],
+                    help="cell fan-in distribution of the synthetic netlist ('irregular' = config E's Zipf skew)")
     ap.add_argument('--mode', default='sweep', choices=['sweep', 'dropin'])
     ap.add_argument('--no-overlap', action='store_true', help='run the sweep and the CNN on one stream')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying one HIP graph')
@@ -145,7 +147,7 @@ def main():
     from mmft import lib
 
     from mmft.dist import design_seeds
-    designs = [synth_design(N=args.nodes, L=args.levels, tile=args.tile, seed=sd)
+    designs = [synth_design(N=args.nodes, L=args.levels, tile=args.tile, seed=sd, fanin=args.fanin)
                for sd in design_seeds(rank, args.designs)]
     log(f'rank {rank}: {len(designs)} designs generated')
     pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=9294)
