@@ -22,9 +22,19 @@
 #include <stdlib.h>
 #include <type_traits>
 
-#ifndef MMFT_GEMM_PF
-#define MMFT_GEMM_PF 1
+// Register prefetch depth (K steps whose global loads are in flight).  A narrow tile has 8-16 MFMAs per wave and K
+// step, so its K loop is a chain of global-load round trips (~1.5 us under load): more steps in flight cost registers,
+// not LDS, and keep the occupancy.  Large tiles hide the latency behind their 64 MFMAs per step (measured: depth 2
+// changes nothing for 128x128).  MMFT_GEMM_PF=<n> forces one depth for every tile (tuning).
+constexpr int gemm_prefetch_depth(int bm, int bn, int bk) {
+#ifdef MMFT_GEMM_PF
+  return MMFT_GEMM_PF;
+#else
+  if (bm * bn >= 128 * 128) return 1;
+  int regs = ((bm * bk + 1023) / 1024 + (bn * bk + 1023) / 1024) * 4;      // VGPRs per in-flight step and thread
+  return regs <= 12 ? 4 : (regs <= 24 ? 2 : 1);
 #endif
+}
 
 namespace mmft {
 
@@ -33,7 +43,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int BM_, int BN_, int BK_, int WM_, int WN_>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
-  static constexpr int PF = MMFT_GEMM_PF;      // register prefetch depth (k-steps in flight)
+  static constexpr int PF = gemm_prefetch_depth(BM_, BN_, BK_);
   static_assert(WM_ * WN_ == 4, "4 waves per workgroup");
   static_assert(BM_ % (16 * WM_) == 0 && BN_ % (16 * WN_) == 0, "tile/wave mismatch");
 };
@@ -154,16 +164,22 @@ struct Im2colMK {
     c.pix0 = img * hw;
     return c;
   }
+  // Branch-free: an out-of-image tap or a k beyond the range loads from a clamped (always valid) address and is
+  // zeroed by a select - the guarded form cost ~20 exec-mask branches per K step on the 16/32-channel layers.
   __device__ __forceinline__ f32x4 load(const Ctx& c, int k, int kend) const {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (k >= kend) return v;
-    int tap = dc.cshift >= 0 ? (k >> dc.cshift) : k / C;
-    int ci = k - tap * C;
+    const bool kin = k < kend;
+    const int kk = kin ? k : 0;
+    int tap = dc.cshift >= 0 ? (kk >> dc.cshift) : kk / C;
+    int ci = kk - tap * C;
     int ky = (tap * dc.kwmagic) >> 16;          // exact for tap < 1000 (taps <= 81 here)
     int kx = tap - ky * KW;
     int yy = c.y + ky - pad, xx = c.x + kx - pad;
-    if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) return v;
-    return *reinterpret_cast<const f32x4*>(p + ((long long)(c.pix0 + yy * W + xx)) * C + ci);
+    const bool ok = kin && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+    yy = ok ? yy : 0;
+    xx = ok ? xx : 0;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p + ((long long)(c.pix0 + yy * W + xx)) * C + ci);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    return ok ? v : z;
   }
 };
 
@@ -194,16 +210,21 @@ struct Im2colKM {
     return c;
   }
   __device__ __forceinline__ f32x4 load(const Ctx& c, int k, int kend) const {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (k >= kend || c.ci < 0) return v;
+    const bool kin = k < kend && c.ci >= 0;
+    const int kk = kin ? k : 0;
     int hw = H * W;
-    int img = dc.hwshift >= 0 ? (k >> dc.hwshift) : k / hw;
-    int rem = k - img * hw;
+    int img = dc.hwshift >= 0 ? (kk >> dc.hwshift) : kk / hw;
+    int rem = kk - img * hw;
     int y = dc.wshift >= 0 ? (rem >> dc.wshift) : rem / W;
     int x = rem - y * W;
     int yy = y + c.dy, xx = x + c.dx;
-    if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) return v;
-    return *reinterpret_cast<const f32x4*>(p + ((long long)(img * hw + yy * W + xx)) * C + c.ci);
+    const bool ok = kin && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+    yy = ok ? yy : 0;
+    xx = ok ? xx : 0;
+    const int ci = c.ci >= 0 ? c.ci : 0;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p + ((long long)(img * hw + yy * W + xx)) * C + ci);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    return ok ? v : z;
   }
 };
 
@@ -364,6 +385,15 @@ __device__ __forceinline__ f32x4 fast_load(const L& l, const C& c, int k, int ke
   else return l.load(c, k, kend);
 }
 
+// MK tiles with BK = 16: a row is 4 16-byte chunks at stride BK + 8 = 24 dwords, so rows r and r + 1 written by 8
+// consecutive lanes overlap in two of the eight 16-byte bank groups (33 % LDS conflict cycles measured).  Rows r and
+// r + 2 do not: lanes 4-7 of every 8 take the row two further (rows 0,2,1,3 within each block of four).
+template <int BK>
+__device__ __forceinline__ int lds_row_swizzle(int r) {
+  if (BK == 16) return (r & ~3) | ((r & 1) << 1) | ((r >> 1) & 1);
+  return r;
+}
+
 template <bool KMAJOR, int S>
 __device__ __forceinline__ void read_frag(const float* tile, int row0, int kb, int lane, float (&f)[4]) {
   if (!KMAJOR) {
@@ -417,6 +447,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(XL xl, WL wl, Epi epi, in
       xo[i] = kk * XS + m4 * 4;
     } else {
       int r = g / (BK / 4), k4 = g % (BK / 4);
+      r = lds_row_swizzle<BK>(r);
       xc[i] = xl.ctx(m0 + r);
       xk[i] = k4 * 4;
       xo[i] = r * XS + k4 * 4;
@@ -432,6 +463,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(XL xl, WL wl, Epi epi, in
       wo[i] = kk * WS + n4 * 4;
     } else {
       int r = g / (BK / 4), k4 = g % (BK / 4);
+      r = lds_row_swizzle<BK>(r);
       wc[i] = wl.ctx(n0 + r);
       wk[i] = k4 * 4;
       wo[i] = r * WS + k4 * 4;
@@ -512,42 +544,34 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(XL xl, WL wl, Epi epi, in
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[b][s], xf[a][s], acc[a][b], 0, 0, 0);
     }
   };
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, PF - 1>;
-
-  if (PF == 1) {
-    if (nk > 0) {
-      gload(S0{}, kbeg);
-      lstore(S0{}, 0);
+  static_assert(PF == 1 || PF == 2 || PF == 4, "prefetch depth");
+  // Step tau multiplies LDS buffer tau & 1.  Register set j = tau % PF held tile tau; it went to LDS during step
+  // tau - 1, so step tau starts by loading tile tau + PF into it and ends by moving tile tau + 1 (set (j + 1) % PF,
+  // requested PF - 1 steps ago) to the other LDS buffer.  The set index is a compile-time constant (unrolled by PF).
+  auto prologue = [&](auto self, auto jc) -> void {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j < PF) {
+      if (j < nk) gload(std::integral_constant<int, j>{}, kbeg + j * BK);
+      self(self, std::integral_constant<int, j + 1>{});
     }
-    __syncthreads();
-    int buf = 0;
-    for (int t = 0; t < nk; ++t) {
-      if (t + 1 < nk) gload(S0{}, kbeg + (t + 1) * BK);
-      multiply(buf);
-      if (t + 1 < nk) lstore(S0{}, buf ^ 1);
-      __syncthreads();
-      buf ^= 1;
-    }
-  } else {
-    if (nk > 0) gload(S0{}, kbeg);
-    if (nk > 1) gload(S1{}, kbeg + BK);
-    if (nk > 0) lstore(S0{}, 0);
-    __syncthreads();
-    // even step t: set 0 is free (tile t sits in LDS), set 1 holds tile t+1; odd steps mirror that
-    for (int t = 0; t < nk; t += 2) {
-      if (t + 2 < nk) gload(S0{}, kbeg + (t + 2) * BK);
-      multiply(0);
-      if (t + 1 < nk) lstore(S1{}, 1);
-      __syncthreads();
-      if (t + 1 < nk) {
-        if (t + 3 < nk) gload(S1{}, kbeg + (t + 3) * BK);
-        multiply(1);
-        if (t + 2 < nk) lstore(S0{}, 0);
+  };
+  prologue(prologue, std::integral_constant<int, 0>{});
+  if (nk > 0) lstore(std::integral_constant<int, 0>{}, 0);
+  __syncthreads();
+  auto substeps = [&](auto self, auto jc, int t) -> void {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j < PF) {
+      const int tau = t + j;
+      if (tau < nk) {
+        if (tau + PF < nk) gload(std::integral_constant<int, j>{}, kbeg + (tau + PF) * BK);
+        multiply(tau & 1);
+        if (tau + 1 < nk) lstore(std::integral_constant<int, (j + 1) % PF>{}, (tau + 1) & 1);
         __syncthreads();
+        self(self, std::integral_constant<int, j + 1>{}, t);
       }
     }
-  }
+  };
+  for (int t = 0; t < nk; t += PF) substeps(substeps, std::integral_constant<int, 0>{}, t);
 
 #pragma unroll
   for (int a = 0; a < RT; ++a)
