@@ -3,6 +3,7 @@
 // ConvTranspose2d(k2,s2), region copies for cat/pad, NCHW<->NHWC.
 // Replaces the torch modules inside the reference's src/Unet.py:8-119 and LayoutNet (src/model.py:216-247).
 #include "gemm_engine.h"
+#include "conv_direct.h"
 
 namespace mmft {
 
@@ -24,6 +25,8 @@ __global__ void __launch_bounds__(256) dgrad_weight_kernel(const float* __restri
 
 static int conv_fwd_launch(const float* x, const float* w, const float* bias, float* y, int Nimg, int H, int W, int Ci,
                            int Co, int KH, int KW, int pad, int act, float slope, hipStream_t st) {
+  if (conv_direct_ok(x, w, bias, y, W, Ci, Co, KH, KW, pad))
+    return conv_direct_launch(x, w, bias, y, Nimg, H, W, Ci, Co, act, slope, st);
   int M = Nimg * H * W, N = Co, K = KH * KW * Ci;
   DenseMK wl{w, nullptr, K, N, (K % 4 == 0) && aligned16(w)};
   Epi epi{y, Co, nullptr, bias, nullptr, nullptr, 0, EPI_STORE, act, slope, 0, (Co % 4 == 0) && aligned16(y)};

@@ -117,6 +117,27 @@ def test_linear_wgrad_indexed(dev):
     assert rel_err(dw, ref) < TOL and rel_err(db, g.double()[idx.long()].sum(0)) < TOL
 
 
+@pytest.mark.parametrize('N,H,W,Ci,Co', [(2, 9, 64, 16, 16), (1, 64, 128, 16, 32), (3, 5, 192, 32, 16), (2, 33, 64, 32, 32),
+                                        (2, 7, 40, 16, 16), (1, 12, 64, 64, 16), (2, 6, 64, 8, 32)])
+def test_conv3x3_forward_dgrad_wgrad(dev, N, H, W, Ci, Co):
+    """3x3 / pad 1 convolution through the C ABI vs fp64 torch: the first four shapes take the direct narrow-channel
+    kernel (Ci, Co in {16, 32}, W % 64 == 0), the others the implicit-GEMM engine; borders, bias and ReLU included."""
+    x = T((N, Ci, H, W), 1, dev).contiguous(memory_format=torch.channels_last)
+    w = T((Co, Ci, 3, 3), 2, dev).contiguous(memory_format=torch.channels_last)
+    b = T((Co,), 3, dev)
+    gy = T((N, Co, H, W), 4, dev).contiguous(memory_format=torch.channels_last)
+    F = torch.nn.functional
+    x64 = x.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    y64 = F.conv2d(x64, w64, b.double(), padding=1)
+    assert rel_err(ops.conv2d_fwd(x, w, b, 1), y64) < TOL
+    assert rel_err(ops.conv2d_fwd(x, w, None, 1, act=ops.ACT_RELU), torch.relu(F.conv2d(x64, w64, None, padding=1))) < TOL
+    y64.backward(gy.double())
+    assert rel_err(ops.conv2d_dgrad(gy, w, 1), x64.grad) < TOL
+    dw = ops.conv2d_wgrad(x, gy, 3, 3, 1)                       # [Co][KH][KW][Ci]
+    assert rel_err(dw.permute(0, 3, 1, 2), w64.grad) < TOL
+
+
 def test_act(dev):
     x = T((1000, 7), 1, dev)
     y = ops.act_fwd(x, ops.ACT_LEAKY, 0.1)
