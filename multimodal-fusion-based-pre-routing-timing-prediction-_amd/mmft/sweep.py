@@ -63,13 +63,20 @@ class SweepState:
             self._bufs[name] = b
         return b
 
-    def begin_backward(self):
+    def begin_backward(self, zero_da=True):
+        """zero_da=False (whole-sweep entry): every DA row the reverse pull reads belongs to a cell node of a level >= 2,
+        and the reverse sweep writes that row (fc_cell_neigh's input gradient) before any lower level pulls from it,
+        so the 268 MB fill per step is skipped; the per-level drop-in form keeps it (a caller may stop a sweep early)."""
         if not self.bwd_active:
             if self.G is None:
                 self.G = self._buf('G', self.D)
+                fresh = 'DA' not in self._bufs
                 self.DA = self._buf('DA', self.D)
+                if fresh:
+                    self.DA.zero_()
             self.G.zero_()
-            self.DA.zero_()
+            if zero_da:
+                self.DA.zero_()
             self.bwd_active = True
 
 
@@ -361,7 +368,7 @@ class SweepFn(torch.autograd.Function):
     def backward(ctx, gout):
         st, g = ctx.state, ctx.state.graph
         st.bwd_active = False
-        st.begin_backward()
+        st.begin_backward(zero_da=False)
         if ctx.tix.numel():
             ops.scatter_add_rows(st.G, ctx.tix, gout if gout.is_contiguous() else gout.contiguous())
         P = [_w(p) for p in st.params]
