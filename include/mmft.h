@@ -268,6 +268,11 @@ long long mmft_levelize_workspace_bytes(int n);
 int mmft_levelize(const int* out_indptr0, const int* out_indices0, const int* out_indptr1, const int* out_indices1,
                   int n, const int* pis, int npi, int* level, int* num_levels, void* workspace,
                   long long workspace_bytes, int device, void* stream);
+/* One level of the fan-in-cone closure (the reference carries the idea unused): every node of
+ * rows[0..n) (or row0 + i) whose mark is set marks all its in-neighbours.  Called for levels L-1 .. 1 after the sampled
+ * endpoints were marked, it leaves mark = 1 exactly on the nodes that can influence those endpoints. */
+int mmft_fanin_cone_step(const int* rows, int row0, int n, const int* in_indptr0, const int* in_indices0,
+                         const int* in_indptr1, const int* in_indices1, unsigned char* mark, int device, void* stream);
 /* One critical path per endpoint (src/verilog_parser_asap7.py:1433-1450, find_critical_path): walk back while the
  * level is >= 2, each time to the FIRST in-neighbour (CSR 0 then CSR 1, insertion order) exactly one level below;
  * an in-neighbour flagged in `stop` (the reference's 'clk' name test; may be NULL) met first ends the walk.

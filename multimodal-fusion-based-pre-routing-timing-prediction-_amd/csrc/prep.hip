@@ -60,6 +60,22 @@ __global__ void __launch_bounds__(256) levelize_seed_kernel(const int* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------- fan-in cone
+// One step of the backward closure: every marked node of the given level marks its in-neighbours (SURVEY.md 8f-1:
+// only the transitive fan-in of the sampled endpoints can influence their predictions).  All writers store 1.
+__global__ void __launch_bounds__(256) cone_step_kernel(const int* __restrict__ rows, int row0, int n,
+                                                        const int* __restrict__ p0, const int* __restrict__ i0,
+                                                        const int* __restrict__ p1, const int* __restrict__ i1,
+                                                        unsigned char* __restrict__ mark) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int v = rows ? rows[i] : row0 + i;
+  if (!mark[v]) return;
+  for (int e = p0[v]; e < p0[v + 1]; ++e) mark[i0[e]] = 1;
+  if (p1)
+    for (int e = p1[v]; e < p1[v + 1]; ++e) mark[i1[e]] = 1;
+}
+
 // ---------------------------------------------------------------------------------------------- critical paths
 // One thread per endpoint walks back through the in-edges: at every step the FIRST predecessor (in CSR = insertion
 // order, as networkx's predecessors()) that sits exactly one level below is taken; a predecessor flagged in `stop`
@@ -304,6 +320,18 @@ int mmft_levelize(const int* out_indptr0, const int* out_indices0, const int* ou
   }
   *num_levels = host_active + 1;                           // levels 0 .. host_active
   return MMFT_OK;
+}
+
+int mmft_fanin_cone_step(const int* rows, int row0, int n, const int* in_indptr0, const int* in_indices0,
+                         const int* in_indptr1, const int* in_indices1, unsigned char* mark, int device, void* stream) {
+  MMFT_REQUIRE(n >= 0 && row0 >= 0, "fanin_cone_step: bad sizes");
+  if (n == 0) return MMFT_OK;
+  MMFT_REQUIRE(in_indptr0 && mark, "fanin_cone_step: null pointer");
+  MMFT_REQUIRE((in_indptr1 == nullptr) == (in_indices1 == nullptr), "fanin_cone_step: second CSR needs both arrays");
+  DeviceGuard dg(device);
+  hipLaunchKernelGGL(cone_step_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, rows, row0, n, in_indptr0,
+                     in_indices0, in_indptr1, in_indices1, mark);
+  return check_launch("fanin_cone_step");
 }
 
 int mmft_trace_critical_paths(const int* in_indptr0, const int* in_indices0, const int* in_indptr1,

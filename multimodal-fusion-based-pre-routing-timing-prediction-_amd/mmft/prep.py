@@ -58,6 +58,32 @@ def level_lists(level, num_levels):
     return out
 
 
+def fanin_cone(in_csrs, level_nodes, targets):
+    """Per-level node lists restricted to the transitive fan-in of `targets` (int32 device tensor of node ids).
+
+    level_nodes: per level an int32 device tensor (or a (start, n) range) of that level's nodes, as the sweep takes
+    them.  The returned lists (int32 device tensors, original order kept) can be passed to PathModel.forward_sweep in
+    place of the full levels: predictions for `targets` are unchanged, nodes outside the cone are never touched.
+    Synchronises once per level (boolean compaction); meant for queries on few endpoints, not for the training step."""
+    p = _csr_pair(in_csrs)
+    ops._chk(targets, 'targets', torch.int32)
+    n_nodes = p[0].numel() - 1
+    mark = torch.zeros(n_nodes, dtype=torch.uint8, device=targets.device)
+    if targets.numel():
+        if int(targets.min()) < 0 or int(targets.max()) >= n_nodes:
+            raise ValueError('fanin_cone: target id outside the node set')
+        mark[targets.long()] = 1
+    dev, st = lib.stream_args(mark)
+    specs = [ops._rowspec(nodes, n_nodes, 'level_nodes') for nodes in level_nodes]
+    for idx, row0, n in reversed(specs[1:]):
+        lib.call('mmft_fanin_cone_step', idx, row0, n, p[0], p[1], p[2], p[3], mark, dev, st)
+    out = []
+    for idx, row0, n in specs:
+        ids = idx if idx is not None else torch.arange(row0, row0 + n, dtype=torch.int32, device=mark.device)
+        out.append(ids[mark[ids.long()].bool()].contiguous())
+    return out
+
+
 def trace_critical_paths(in_csrs, level, endpoints, stop=None, maxlen=None):
     """paths int32[P, maxlen] (-1 padded, endpoint first) and lens int32[P]; `stop`: optional uint8 flags per node."""
     p = _csr_pair(in_csrs)

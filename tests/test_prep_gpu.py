@@ -7,6 +7,7 @@ import torch
 
 from oracle import prep_restatement as PR
 from test_prep_cpu import random_dag
+from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -126,3 +127,43 @@ def test_levelize_reproduces_synthetic_levels_full_size(dev, cfg):
     steps = lv[pl[:, :-1]] - lv[pl[:, 1:]]
     valid = torch.arange(paths.shape[1] - 1, device=dev)[None, :] < (lens[:, None] - 1)
     assert bool(((steps == 1) | ~valid).all())
+
+
+def test_fanin_cone_pruned_sweep_equals_full_sweep(dev):
+    """restricting every level to the transitive fan-in of the sampled endpoints leaves their embeddings
+    (and the parameter gradients) unchanged; only a fraction of the nodes is touched."""
+    from mmft import prep
+    from mmft import sweep as S
+    from mmft.synth import synth_design
+    from mmft.train import build_models, DesignBatch
+    d = synth_design(N=20000, L=24, tile=32, seed=77, end_frac=0.2)
+    b = DesignBatch([d], dev)
+    pmodel, _ = build_models(map_size=d.map_size, device=dev, seed=5)
+    g = b.graph
+    ends, _, _, _, _, _ = b.select([[3, 11, 11, 40]])                       # a few endpoints (one duplicated)
+    in_csrs = [g.csr('in', 'net'), g.csr('in', 'cell')]
+    cone = prep.fanin_cone(in_csrs, [torch.tensor(l, dtype=torch.int32, device=dev) for l in b.level_nodes], ends)
+    frac = sum(c.numel() for c in cone) / sum(len(l) for l in b.level_nodes)
+    assert 0 < frac < 0.5, frac
+    # brute-force closure on the host
+    ip0, ix0 = [t.cpu().numpy() for t in in_csrs[0]]
+    ip1, ix1 = [t.cpu().numpy() for t in in_csrs[1]]
+    seen, stack = set(ends.cpu().tolist()), list(set(ends.cpu().tolist()))
+    while stack:
+        v = stack.pop()
+        for u in list(ix0[ip0[v]:ip0[v + 1]]) + list(ix1[ip1[v]:ip1[v + 1]]):
+            if u not in seen:
+                seen.add(int(u)); stack.append(int(u))
+    assert sorted(seen) == sorted(int(v) for c in cone for v in c.cpu().tolist())
+    res = []
+    for levels in (b.level_nodes, cone):
+        g.ndata['h'] = torch.zeros((b.N, 128), dtype=torch.float32, device=dev)
+        for p in pmodel.gnn.parameters():
+            p.grad = None
+        h = S.sweep_forward_all(pmodel.gnn, g, levels, ends)
+        (h * h).sum().backward()
+        res.append((h.detach().clone(), {k: p.grad.clone() for k, p in pmodel.gnn.named_parameters() if p.grad is not None}))
+    assert rel_err(res[1][0], res[0][0]) < 1e-6
+    assert res[0][1].keys() == res[1][1].keys()
+    for k in res[0][1]:
+        assert rel_err(res[1][1][k], res[0][1][k]) < 1e-4, k
