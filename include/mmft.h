@@ -225,6 +225,14 @@ int mmft_transpose(const float* src, float* dst, int R, int C, int device, void*
 int mmft_masked_fc_fwd(const int* mask_indptr, const int* mask_cols, const int* paths, const int* f_off, int T,
                        const float* f, const float* wT, const float* bias, float* out, int P, int Dout,
                        int device, void* stream);
+/* The same projection when the masks are given as runs of consecutive cells (path masks are unions of boxes,
+ * src/verilog_parser_asap7.py:1326-1334): GP[b*P + c] = sum of f * wT over the cells <= c of c's block of S cells
+ * (prefix), then out[t] = bias + sum over the runs [s, e] of path t of GP[e] - GP[s - 1] (runs never cross a block). */
+int mmft_masked_fc_prefix(const float* f, const float* wT, float* GP, int B, int P, int Dout, int S, int device,
+                          void* stream);
+int mmft_masked_fc_fwd_runs(const int* run_ptr, const int* run_start, const int* run_len, const int* paths,
+                            const int* f_off, int T, const float* GP, const float* bias, float* out, int Dout, int S,
+                            int device, void* stream);
 /* Backward of the masked projection as a deterministic GATHER over the transposed masks (no atomics):
  * csc_indptr[B*P+1] / csc_paths[nnz] list, for every map cell (b, p), the path ids whose mask covers it
  * (ascending); first[q] is the first batch row holding path q (-1: not sampled) and next[t] the next batch

@@ -70,6 +70,66 @@ __global__ void __launch_bounds__(256) masked_fc_fwd_kernel(const int* __restric
   }
 }
 
+// ---- the same projection through block-prefix sums (path masks are unions of boxes = runs of consecutive cells) ----
+// GP[b*P + c][:] = sum over the cells c' <= c of c's block of S consecutive cells of f[b*P + c'] * wT[c'][:].
+// One thread per (design, block, 4-channel group) scans its S cells; the loads do not depend on the running sum.
+__global__ void __launch_bounds__(256) fc_prefix_kernel(const float* __restrict__ f, const float* __restrict__ wT,
+                                                        float* __restrict__ GP, int B, int P, int Dout, int S) {
+  const int groups = Dout >> 2, nblk = P / S;
+  const long long total = (long long)B * nblk * groups;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    int c4 = (int)(t % groups);
+    long long rest = t / groups;
+    int blk = (int)(rest % nblk), b = (int)(rest / nblk);
+    const float* w = wT + (long long)blk * S * Dout + c4 * 4;
+    const float* fb = f + (long long)b * P + (long long)blk * S;
+    float* g = GP + ((long long)b * P + (long long)blk * S) * Dout + c4 * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int y = 0; y < S; ++y) {
+      acc += *reinterpret_cast<const f32x4*>(w + (long long)y * Dout) * fb[y];
+      *reinterpret_cast<f32x4*>(g + (long long)y * Dout) = acc;
+    }
+  }
+}
+
+// one workgroup per batch row: a run [s, e] of the mask contributes GP[e] - GP[s-1] (GP[e] alone at a block start):
+// two 16-byte reads per thread and run instead of one per cell; partials combined through LDS in fixed order
+__global__ void __launch_bounds__(256) masked_fc_fwd_runs_kernel(const int* __restrict__ run_ptr,
+                                                                 const int* __restrict__ run_start,
+                                                                 const int* __restrict__ run_len,
+                                                                 const int* __restrict__ paths,
+                                                                 const int* __restrict__ foff, int T,
+                                                                 const float* __restrict__ GP,
+                                                                 const float* __restrict__ bias, float* __restrict__ out,
+                                                                 int Dout, int S) {
+  __shared__ f32x4 part[256];
+  const int groups = Dout >> 2;
+  const int J = 256 / groups;
+  const int t = blockIdx.x;
+  const int j = threadIdx.x / groups, c4 = threadIdx.x - j * groups;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (j < J) {
+    int q = paths[t];
+    const float* gb = GP + (long long)(foff ? foff[t] : 0) * Dout + c4 * 4;
+    int r1 = run_ptr[q + 1];
+    for (int r = run_ptr[q] + j; r < r1; r += J) {
+      int s = run_start[r], e = s + run_len[r] - 1;
+      f32x4 hi = *reinterpret_cast<const f32x4*>(gb + (long long)e * Dout);
+      f32x4 lo = {0.f, 0.f, 0.f, 0.f};
+      if (s % S) lo = *reinterpret_cast<const f32x4*>(gb + (long long)(s - 1) * Dout);
+      acc += hi - lo;
+    }
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < groups) {
+    f32x4 sum = bias ? *reinterpret_cast<const f32x4*>(bias + threadIdx.x * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int jj = 0; jj < J; ++jj) sum += part[jj * groups + threadIdx.x];
+    *reinterpret_cast<f32x4*>(out + (long long)t * Dout + threadIdx.x * 4) = sum;
+  }
+}
+
 // one thread per (map cell p, 4-channel group), looping over the designs b: gathers the batch rows covering
 // cell (b,p) through the transposed masks (fixed order -> bitwise reproducible); df by an LDS reduction
 __global__ void __launch_bounds__(256) masked_fc_bwd_kernel(const int* __restrict__ cptr, const int* __restrict__ cpaths,
@@ -223,6 +283,32 @@ int mmft_masked_fc_fwd(const int* mask_indptr, const int* mask_cols, const int* 
   DeviceGuard dg(device);
   MMFT_LAUNCH("masked_fc_fwd_kernel", 0.0, 0.0, masked_fc_fwd_kernel, dim3(T), dim3(256), (hipStream_t)stream, mask_indptr, mask_cols, paths, f_off, T, f, wT, bias, out, Dout);
   return check_launch("masked_fc_fwd");
+}
+
+int mmft_masked_fc_prefix(const float* f, const float* wT, float* GP, int B, int P, int Dout, int S, int device,
+                          void* stream) {
+  MMFT_REQUIRE(f && wT && GP, "masked_fc_prefix: null pointer");
+  MMFT_REQUIRE(B > 0 && P > 0 && S > 0 && P % S == 0 && Dout >= 4 && Dout % 4 == 0 && Dout <= 1024,
+               "masked_fc_prefix: P must be a multiple of the block size, Dout a multiple of 4 in [4, 1024]");
+  MMFT_REQUIRE(aligned16(wT) && aligned16(GP), "masked_fc_prefix: 16-byte alignment");
+  DeviceGuard dg(device);
+  long long total = (long long)B * (P / S) * (Dout / 4);
+  MMFT_LAUNCH("fc_prefix_kernel", 0.0, 4.0 * ((double)B * P * Dout + (double)P * Dout + (double)B * P), fc_prefix_kernel,
+              dim3(ew_grid(total)), dim3(256), (hipStream_t)stream, f, wT, GP, B, P, Dout, S);
+  return check_launch("masked_fc_prefix");
+}
+
+int mmft_masked_fc_fwd_runs(const int* run_ptr, const int* run_start, const int* run_len, const int* paths,
+                            const int* f_off, int T, const float* GP, const float* bias, float* out, int Dout, int S,
+                            int device, void* stream) {
+  MMFT_REQUIRE(T >= 0 && S > 0 && Dout >= 4 && Dout % 4 == 0 && Dout <= 1024, "masked_fc_fwd_runs: bad sizes");
+  if (T == 0) return MMFT_OK;
+  MMFT_REQUIRE(run_ptr && run_start && run_len && paths && GP && out, "masked_fc_fwd_runs: null pointer");
+  MMFT_REQUIRE(aligned16(GP) && aligned16(out) && (!bias || aligned16(bias)), "masked_fc_fwd_runs: 16-byte alignment");
+  DeviceGuard dg(device);
+  MMFT_LAUNCH("masked_fc_fwd_runs_kernel", 0.0, 0.0, masked_fc_fwd_runs_kernel, dim3(T), dim3(256), (hipStream_t)stream, run_ptr,
+              run_start, run_len, paths, f_off, T, GP, bias, out, Dout, S);
+  return check_launch("masked_fc_fwd_runs");
 }
 
 int mmft_masked_fc_bwd(const int* csc_indptr, const int* csc_paths, const int* first, const int* next, const float* gout,

@@ -22,6 +22,26 @@ def _csc_from_csr(indptr, cols, P):
     return cptr, rows[order]
 
 
+RUN_BLOCK = 64          # cells per prefix block (mmft_masked_fc_prefix); 0 disables the run form
+USE_RUNS = True         # MaskedFcFn.forward: prefix sums + runs when the masks offer them (False: one gather per cell)
+
+
+def _runs_from_csr(indptr, cols, S):
+    """(run_ptr[rows+1], run_start[R], run_len[R]) of a CSR with ascending columns per row; a run ends where the next
+    column is not the successor, at a row end, and at every multiple of S."""
+    n = cols.shape[0]
+    rows = indptr.shape[0] - 1
+    if n == 0:
+        return np.zeros(rows + 1, dtype=np.int64), np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+    new = np.ones(n, dtype=bool)
+    new[1:] = (cols[1:] != cols[:-1] + 1) | (cols[1:] % S == 0)
+    new[indptr[:-1][np.diff(indptr) > 0]] = True
+    starts = np.nonzero(new)[0]
+    run_len = np.diff(np.append(starts, n))
+    run_ptr = np.searchsorted(starts, indptr, side='left')
+    return run_ptr.astype(np.int64), cols[starts], run_len
+
+
 class PathMasks:
     """Device CSR (+ transposed CSC) of path masks, num_paths x P, 0/1  (src/verilog_parser_asap7.py:1302-1369).
 
@@ -45,6 +65,15 @@ class PathMasks:
         cptr, cpaths = _csc_from_csr(ip, cell, self.B * self.P)
         self.csc_indptr = torch.from_numpy(cptr.astype(np.int32)).to(device)
         self.csc_paths = torch.from_numpy(cpaths.astype(np.int32)).to(device)
+        # run-length form of the rows for the prefix-sum projection: runs of consecutive cells that do not cross a
+        # block of RUN_BLOCK cells (box masks: ~70 runs for ~580 cells per path)
+        self.run_block = RUN_BLOCK if self.P % RUN_BLOCK == 0 else 0
+        if self.run_block:
+            rp, rs, rl = _runs_from_csr(ip, cc, self.run_block)
+            self.run_ptr = torch.from_numpy(rp.astype(np.int32)).to(device)
+            self.run_start = torch.from_numpy(rs.astype(np.int32)).to(device)
+            self.run_len = torch.from_numpy(rl.astype(np.int32)).to(device)
+            self.num_runs = int(rs.shape[0])
 
     @staticmethod
     def batch(masks):
@@ -117,8 +146,15 @@ class MaskedFcFn(torch.autograd.Function):
         wT = torch.empty((P, Dout), dtype=torch.float32, device=f.device)
         lib.call('mmft_transpose', wc, wT, Dout, P, dev, st)
         out = torch.empty((T, Dout), dtype=torch.float32, device=f.device)
-        lib.call('mmft_masked_fc_fwd', pm.masks.indptr, pm.masks.cols, pm.paths, pm.f_off, T, f, wT, b, out, P, Dout,
-                 dev, st)
+        m = pm.masks
+        if USE_RUNS and m.run_block and f.numel() == m.B * P:
+            # block-prefix sums of f * wT once per step, then two reads per run of a path instead of one per cell
+            GP = torch.empty((m.B * P, Dout), dtype=torch.float32, device=f.device)
+            lib.call('mmft_masked_fc_prefix', f, wT, GP, m.B, P, Dout, m.run_block, dev, st)
+            lib.call('mmft_masked_fc_fwd_runs', m.run_ptr, m.run_start, m.run_len, pm.paths, pm.f_off, T, GP, b, out, Dout,
+                     m.run_block, dev, st)
+        else:
+            lib.call('mmft_masked_fc_fwd', m.indptr, m.cols, pm.paths, pm.f_off, T, f, wT, b, out, P, Dout, dev, st)
         ctx.pm, ctx.fshape = pm, feat_map.shape
         ctx.has_bias = b is not None
         ctx.sinks = (gradsink.of(w) if wc is w else None, gradsink.of(b))

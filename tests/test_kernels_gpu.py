@@ -138,6 +138,58 @@ def test_conv3x3_forward_dgrad_wgrad(dev, N, H, W, Ci, Co):
     assert rel_err(dw.permute(0, 3, 1, 2), w64.grad) < TOL
 
 
+@pytest.mark.parametrize('B', [1, 3])
+def test_masked_fc_runs_equal_cells_and_dense(dev, B):
+    """Masked projection: prefix-sum / run form vs one gather per cell vs the dense fp64 product, forward and backward
+    (box masks, duplicated paths, an empty mask row, runs that cross the 64-cell prefix blocks)."""
+    from mmft import fusion
+    from mmft.fusion import PathMasks, MaskedPathMap, masked_fc
+    rng = np.random.default_rng(5 + B)
+    m, Dout, npaths = 64, 128, 40
+    P = m * m
+    masks = []
+    for b in range(B):
+        ip, cols = [0], []
+        for p in range(npaths):
+            cells = set()
+            for _ in range(int(rng.integers(0, 6)) if p else 0):              # path 0: empty mask
+                x0, y0, w, h = rng.integers(0, m - 12), rng.integers(0, m - 12), rng.integers(1, 12), rng.integers(1, 12)
+                cells.update(int(x * m + y) for x in range(x0, x0 + w) for y in range(y0, y0 + h))
+            c = sorted(cells)
+            cols += c
+            ip.append(len(cols))
+        masks.append(PathMasks(np.array(ip), np.array(cols, dtype=np.int64), P, dev))
+    pmk = masks[0] if B == 1 else PathMasks.batch(masks)
+    assert pmk.run_block == 64 and 0 < pmk.num_runs < pmk.host_cols.shape[0]
+    paths = rng.integers(0, B * npaths, size=70)
+    paths[:3] = [0, 5, 5]
+    feat = T((B, P), 1, dev).requires_grad_(True)
+    w = T((Dout, P), 2, dev, -0.05, 0.05).requires_grad_(True)
+    bias = T((Dout,), 3, dev).requires_grad_(True)
+    gout = T((70, Dout), 4, dev)
+    res = {}
+    for use_runs in (True, False):
+        fusion.USE_RUNS = use_runs
+        try:
+            for t in (feat, w, bias):
+                t.grad = None
+            out = masked_fc(MaskedPathMap(pmk, paths, feat), w, bias)
+            out.backward(gout)
+            res[use_runs] = (out.detach().clone(), feat.grad.clone(), w.grad.clone(), bias.grad.clone())
+        finally:
+            fusion.USE_RUNS = True
+    dense = torch.zeros((70, P), dtype=torch.float64, device=dev)
+    for t, q in enumerate(paths):
+        b = int(pmk.row_design[q])
+        c = torch.from_numpy(pmk.host_cols[pmk.host_indptr[q]:pmk.host_indptr[q + 1]]).to(dev)
+        dense[t, c] = feat.detach().double()[b, c]
+    ref = dense @ w.detach().double().t() + bias.detach().double()
+    assert rel_err(res[True][0], ref) < TOL and rel_err(res[False][0], ref) < TOL
+    assert rel_err(res[True][0], res[False][0]) < 1e-5
+    for a, b_ in zip(res[True][1:], res[False][1:]):
+        assert torch.equal(a, b_)                                             # the backward is the same kernel
+
+
 def test_act(dev):
     x = T((1000, 7), 1, dev)
     y = ops.act_fwd(x, ops.ACT_LEAKY, 0.1)
