@@ -130,6 +130,83 @@ __global__ void __launch_bounds__(256) masked_fc_fwd_runs_kernel(const int* __re
   }
 }
 
+// ---- backward of the run form --------------------------------------------------------------------------------
+// Stage 1: D[b*P + c] = sum of gout over the batch rows whose path has a run ENDING at cell c, minus those with a
+// run STARTING at c + 1 (inside the same block).  `code` >= 0: path id, run end; < 0: path id = -code - 1, run start.
+// One thread per (cell, 4-channel group); four boundary entries per trip keep their index -> row chains overlapped.
+__global__ void __launch_bounds__(256) masked_fc_bwd_runs_d_kernel(const int* __restrict__ bptr, const int* __restrict__ bcode,
+                                                                   const int* __restrict__ first,
+                                                                   const int* __restrict__ next,
+                                                                   const float* __restrict__ gout, float* __restrict__ D,
+                                                                   long long cells, int Dout) {
+  const int groups = Dout >> 2;
+  const long long total = cells * groups;
+  for (long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; t0 < total; t0 += (long long)gridDim.x * blockDim.x) {
+    long long cell = t0 / groups;
+    int c4 = (int)(t0 - cell * groups);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    auto rowsum = [&](int t) {                        // duplicates of a path in the batch: rare, summed in batch order
+      f32x4 sum = z;
+      for (; t >= 0; t = next[t]) sum += *reinterpret_cast<const f32x4*>(gout + (long long)t * Dout + c4 * 4);
+      return sum;
+    };
+    int e = bptr[cell], e1 = bptr[cell + 1];
+    for (; e + 4 <= e1; e += 4) {                     // four index -> batch-row -> gradient-row chains in flight
+      int k0 = bcode[e], k1 = bcode[e + 1], k2 = bcode[e + 2], k3 = bcode[e + 3];
+      int t0 = first[k0 >= 0 ? k0 : -k0 - 1], t1 = first[k1 >= 0 ? k1 : -k1 - 1];
+      int t2 = first[k2 >= 0 ? k2 : -k2 - 1], t3 = first[k3 >= 0 ? k3 : -k3 - 1];
+      f32x4 r0 = t0 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t0 * Dout + c4 * 4) : z;
+      f32x4 r1 = t1 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t1 * Dout + c4 * 4) : z;
+      f32x4 r2 = t2 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t2 * Dout + c4 * 4) : z;
+      f32x4 r3 = t3 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t3 * Dout + c4 * 4) : z;
+      if (t0 >= 0) r0 += rowsum(next[t0]);
+      if (t1 >= 0) r1 += rowsum(next[t1]);
+      if (t2 >= 0) r2 += rowsum(next[t2]);
+      if (t3 >= 0) r3 += rowsum(next[t3]);
+      acc = k0 >= 0 ? acc + r0 : acc - r0;
+      acc = k1 >= 0 ? acc + r1 : acc - r1;
+      acc = k2 >= 0 ? acc + r2 : acc - r2;
+      acc = k3 >= 0 ? acc + r3 : acc - r3;
+    }
+    for (; e < e1; ++e) {
+      int code = bcode[e];
+      f32x4 sum = rowsum(first[code >= 0 ? code : -code - 1]);
+      acc = code >= 0 ? acc + sum : acc - sum;
+    }
+    *reinterpret_cast<f32x4*>(D + cell * Dout + c4 * 4) = acc;
+  }
+}
+
+// Stage 2: suffix sums of D inside every block of S cells give dg[b][c] = d loss / d (f[b][c] * wT[c]);
+// dwT slab of design b: f * dg; df[b][c] = <dg, wT[c]> reduced over the channel groups of the cell (consecutive lanes).
+// GROUPS = Dout / 4 is a power of two <= 64 so that the reduction is a wave shuffle.
+template <int GROUPS>
+__global__ void __launch_bounds__(256) masked_fc_bwd_runs_scan_kernel(const float* __restrict__ D, const float* __restrict__ f,
+                                                                      const float* __restrict__ wT, float* __restrict__ dwT,
+                                                                      float* __restrict__ df, int B, int P, int S) {
+  constexpr int Dout = GROUPS * 4;
+  const int nblk = P / S;
+  const long long total = (long long)B * nblk * GROUPS;
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;                                  // total is a multiple of GROUPS: whole lane groups exit
+  int c4 = (int)(t % GROUPS);
+  long long rest = t / GROUPS;
+  int blk = (int)(rest % nblk), b = (int)(rest / nblk);
+  const long long cell0 = (long long)b * P + (long long)blk * S;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int y = S - 1; y >= 0; --y) {
+    const long long cell = cell0 + y;
+    acc += *reinterpret_cast<const f32x4*>(D + cell * Dout + c4 * 4);
+    f32x4 w = *reinterpret_cast<const f32x4*>(wT + ((long long)blk * S + y) * Dout + c4 * 4);
+    *reinterpret_cast<f32x4*>(dwT + cell * Dout + c4 * 4) = acc * f[cell];
+    float d = acc.x * w.x + acc.y * w.y + acc.z * w.z + acc.w * w.w;
+#pragma unroll
+    for (int o = GROUPS / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    if (c4 == 0) df[cell] = d;
+  }
+}
+
 // one thread per (map cell p, 4-channel group), looping over the designs b: gathers the batch rows covering
 // cell (b,p) through the transposed masks (fixed order -> bitwise reproducible); df by an LDS reduction
 __global__ void __launch_bounds__(256) masked_fc_bwd_kernel(const int* __restrict__ cptr, const int* __restrict__ cpaths,
@@ -334,6 +411,50 @@ int mmft_masked_fc_bwd(const int* csc_indptr, const int* csc_paths, const int* f
   int rc = check_launch("masked_fc_bwd");
   if (rc) return rc;
   return launch_slab_reduce(workspace, B, (long long)P * Dout, dwT, 0, st);
+}
+
+long long mmft_masked_fc_bwd_runs_workspace_bytes(int B, int P, int Dout) {
+  return (long long)(B > 1 ? 2 : 1) * B * P * Dout * 4;          // D, and per-design dwT slabs when B > 1
+}
+
+int mmft_masked_fc_bwd_runs(const int* bnd_ptr, const int* bnd_code, const int* first, const int* next, const float* gout,
+                            const float* f, const float* wT, float* dwT, float* df, int B, int P, int Dout, int S,
+                            float* workspace, long long workspace_bytes, int device, void* stream) {
+  MMFT_REQUIRE(bnd_ptr && bnd_code && first && next && gout && f && wT && dwT && df, "masked_fc_bwd_runs: null pointer");
+  const int groups = Dout / 4;
+  MMFT_REQUIRE(B > 0 && P > 0 && S > 0 && P % S == 0 && Dout % 4 == 0 && groups >= 1 && groups <= 64 &&
+                   (groups & (groups - 1)) == 0,
+               "masked_fc_bwd_runs: Dout / 4 must be a power of two <= 64, P a multiple of the block size");
+  MMFT_REQUIRE(aligned16(gout) && aligned16(wT) && aligned16(dwT), "masked_fc_bwd_runs: 16-byte alignment");
+  MMFT_REQUIRE(workspace && workspace_bytes >= mmft_masked_fc_bwd_runs_workspace_bytes(B, P, Dout) && aligned16(workspace),
+               "masked_fc_bwd_runs: workspace too small");
+  DeviceGuard dg(device);
+  hipStream_t st = (hipStream_t)stream;
+  const long long cells = (long long)B * P;
+  float* D = workspace;
+  float* slabs = B > 1 ? workspace + cells * Dout : dwT;
+  MMFT_LAUNCH("masked_fc_bwd_runs_d_kernel", 0.0, 0.0, masked_fc_bwd_runs_d_kernel, dim3(ew_grid(cells * groups)), dim3(256), st,
+              bnd_ptr, bnd_code, first, next, gout, D, cells, Dout);
+  int rc = check_launch("masked_fc_bwd_runs_d");
+  if (rc) return rc;
+  const long long total = (long long)B * (P / S) * groups;
+  const dim3 grid((unsigned)((total + 255) / 256));
+#define MMFT_SCAN(G)                                                                                                  \
+  MMFT_LAUNCH("masked_fc_bwd_runs_scan_kernel", 0.0, 4.0 * 3.0 * cells * Dout, masked_fc_bwd_runs_scan_kernel<G>, grid, \
+              dim3(256), st, D, f, wT, slabs, df, B, P, S)
+  switch (groups) {
+    case 1: MMFT_SCAN(1); break;
+    case 2: MMFT_SCAN(2); break;
+    case 4: MMFT_SCAN(4); break;
+    case 8: MMFT_SCAN(8); break;
+    case 16: MMFT_SCAN(16); break;
+    case 32: MMFT_SCAN(32); break;
+    default: MMFT_SCAN(64); break;
+  }
+#undef MMFT_SCAN
+  rc = check_launch("masked_fc_bwd_runs_scan");
+  if (rc || B == 1) return rc;
+  return launch_slab_reduce(slabs, B, (long long)P * Dout, dwT, 0, st);
 }
 
 int mmft_mse_fwd_bwd(const float* pred, const float* target, int n, float* loss, float* grad, int device, void* stream) {

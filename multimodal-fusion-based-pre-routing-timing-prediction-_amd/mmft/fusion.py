@@ -74,6 +74,19 @@ class PathMasks:
             self.run_start = torch.from_numpy(rs.astype(np.int32)).to(device)
             self.run_len = torch.from_numpy(rl.astype(np.int32)).to(device)
             self.num_runs = int(rs.shape[0])
+            # run boundaries per cell (design-major) for the backward: +path at a run's last cell, -(path) - 1 at the
+            # cell before a run that starts inside a block
+            rows_of_run = np.repeat(np.arange(self.num_paths), np.diff(rp))
+            base = self.row_design[rows_of_run] * self.P
+            end_cell = base + rs + rl - 1
+            inner = (rs % self.run_block) != 0
+            cells = np.concatenate([end_cell, (base + rs - 1)[inner]])
+            codes = np.concatenate([rows_of_run, -rows_of_run[inner] - 1])
+            order = np.argsort(cells, kind='stable')
+            bptr = np.zeros(self.B * self.P + 1, dtype=np.int64)
+            np.cumsum(np.bincount(cells, minlength=self.B * self.P), out=bptr[1:])
+            self.bnd_ptr = torch.from_numpy(bptr.astype(np.int32)).to(device)
+            self.bnd_code = torch.from_numpy(codes[order].astype(np.int32)).to(device)
 
     @staticmethod
     def batch(masks):
@@ -171,9 +184,15 @@ class MaskedFcFn(torch.autograd.Function):
         B = pm.masks.B
         dwT = torch.empty_like(wT)
         df = torch.empty(B * P, dtype=torch.float32, device=f.device)
-        ws = lib.workspace(f.device, B * P * Dout * 4 if B > 1 else 0)
-        lib.call('mmft_masked_fc_bwd', pm.masks.csc_indptr, pm.masks.csc_paths, pm.first, pm.next, g, f, wT, dwT, df,
-                 B, P, Dout, ws, ws.numel() * 4, dev, st)
+        groups = Dout // 4
+        if USE_RUNS and pm.masks.run_block and groups <= 64 and groups & (groups - 1) == 0:
+            ws = lib.workspace(f.device, lib.query('mmft_masked_fc_bwd_runs_workspace_bytes', B, P, Dout))
+            lib.call('mmft_masked_fc_bwd_runs', pm.masks.bnd_ptr, pm.masks.bnd_code, pm.first, pm.next, g, f, wT, dwT, df,
+                     B, P, Dout, pm.masks.run_block, ws, ws.numel() * 4, dev, st)
+        else:
+            ws = lib.workspace(f.device, B * P * Dout * 4 if B > 1 else 0)
+            lib.call('mmft_masked_fc_bwd', pm.masks.csc_indptr, pm.masks.csc_paths, pm.first, pm.next, g, f, wT, dwT, df,
+                     B, P, Dout, ws, ws.numel() * 4, dev, st)
         dw = db = None
         if ctx.needs_input_grad[1]:
             def _dw(out):

@@ -186,8 +186,16 @@ def test_masked_fc_runs_equal_cells_and_dense(dev, B):
     ref = dense @ w.detach().double().t() + bias.detach().double()
     assert rel_err(res[True][0], ref) < TOL and rel_err(res[False][0], ref) < TOL
     assert rel_err(res[True][0], res[False][0]) < 1e-5
-    for a, b_ in zip(res[True][1:], res[False][1:]):
-        assert torch.equal(a, b_)                                             # the backward is the same kernel
+    dref = dense.clone().requires_grad_(True)
+    w64, b64, f64 = w.detach().double().requires_grad_(True), bias.detach().double().requires_grad_(True), None
+    (dref @ w64.t() + b64).backward(gout.double())
+    gfeat = torch.zeros((B, P), dtype=torch.float64, device=dev)
+    for t, q in enumerate(paths):                                             # d loss / d feat through the mask rows
+        b = int(pmk.row_design[q])
+        c = torch.from_numpy(pmk.host_cols[pmk.host_indptr[q]:pmk.host_indptr[q + 1]]).to(dev)
+        gfeat[b, c] += dref.grad[t, c]
+    for r in (res[True], res[False]):
+        assert rel_err(r[1], gfeat) < TOL and rel_err(r[2], w64.grad) < TOL and rel_err(r[3], b64.grad) < TOL
 
 
 def test_act(dev):
