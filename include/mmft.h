@@ -234,9 +234,9 @@ int mmft_masked_fc_fwd_runs(const int* run_ptr, const int* run_start, const int*
                             const int* f_off, int T, const float* GP, const float* bias, float* out, int Dout, int S,
                             int device, void* stream);
 /* Backward of the run form: bnd_ptr[B*P + 1] / bnd_code list, per cell (design-major), the paths with a run ending at
- * the cell (code = path id) or starting right after it inside the same block (code = -path id - 1); stage 1 gathers
- * the signed sums of gout, stage 2 turns them into dg by a suffix scan per block and emits dwT (per-design slabs summed
- * in fixed order) and df.  Dout / 4 must be a power of two <= 64. */
+ * the cell (code = path id) or starting right after it inside the same block (code = -path id - 1); one workgroup per
+ * (design, block) gathers the signed sums of gout into LDS, turns them into dg by a suffix scan and emits dwT
+ * (per-design slabs summed in fixed order) and df.  Dout / 4 must be a power of two <= 64, S * Dout * 4 <= 64 KB. */
 long long mmft_masked_fc_bwd_runs_workspace_bytes(int B, int P, int Dout);
 int mmft_masked_fc_bwd_runs(const int* bnd_ptr, const int* bnd_code, const int* first, const int* next, const float* gout,
                             const float* f, const float* wT, float* dwT, float* df, int B, int P, int Dout, int S,

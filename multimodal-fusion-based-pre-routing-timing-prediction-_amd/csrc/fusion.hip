@@ -131,28 +131,34 @@ __global__ void __launch_bounds__(256) masked_fc_fwd_runs_kernel(const int* __re
 }
 
 // ---- backward of the run form --------------------------------------------------------------------------------
-// Stage 1: D[b*P + c] = sum of gout over the batch rows whose path has a run ENDING at cell c, minus those with a
-// run STARTING at c + 1 (inside the same block).  `code` >= 0: path id, run end; < 0: path id = -code - 1, run start.
-// One thread per (cell, 4-channel group); four boundary entries per trip keep their index -> row chains overlapped.
-__global__ void __launch_bounds__(256) masked_fc_bwd_runs_d_kernel(const int* __restrict__ bptr, const int* __restrict__ bcode,
-                                                                   const int* __restrict__ first,
-                                                                   const int* __restrict__ next,
-                                                                   const float* __restrict__ gout, float* __restrict__ D,
-                                                                   long long cells, int Dout) {
-  const int groups = Dout >> 2;
-  const long long total = cells * groups;
-  for (long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; t0 < total; t0 += (long long)gridDim.x * blockDim.x) {
-    long long cell = t0 / groups;
-    int c4 = (int)(t0 - cell * groups);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    auto rowsum = [&](int t) {                        // duplicates of a path in the batch: rare, summed in batch order
-      f32x4 sum = z;
-      for (; t >= 0; t = next[t]) sum += *reinterpret_cast<const f32x4*>(gout + (long long)t * Dout + c4 * 4);
-      return sum;
-    };
-    int e = bptr[cell], e1 = bptr[cell + 1];
-    for (; e + 4 <= e1; e += 4) {                     // four index -> batch-row -> gradient-row chains in flight
+// One workgroup per (design, block of S cells), 256 threads = J entry lanes x GROUPS channel groups.
+// Stage 1: D[c] = sum of gout over the batch rows whose path has a run ENDING at cell c, minus those with a run STARTING
+// at c + 1 inside the block (`code` >= 0: path id, run end; < 0: path id = -code - 1, run start).  Entry lane j owns the
+// cells [j S/J, (j+1) S/J) and walks their boundary lists with four index -> batch-row -> gradient-row chains in flight;
+// D stays in LDS.  Stage 2 (lane 0's channel groups): suffix sums of D give dg[c] = d loss / d(f[c] wT[c]); emit the
+// design's dwT slab (f dg) and df[c] = <dg, wT[c]> (wave-shuffle reduction over the GROUPS lanes).  Fixed orders.
+template <int GROUPS>
+__global__ void __launch_bounds__(256) masked_fc_bwd_runs_kernel(const int* __restrict__ bptr, const int* __restrict__ bcode,
+                                                                 const int* __restrict__ first, const int* __restrict__ next,
+                                                                 const float* __restrict__ gout, const float* __restrict__ f,
+                                                                 const float* __restrict__ wT, float* __restrict__ dwT,
+                                                                 float* __restrict__ df, int P, int S) {
+  constexpr int Dout = GROUPS * 4, J = 256 / GROUPS;
+  extern __shared__ __attribute__((aligned(16))) float dl[];            // [S][Dout]
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const int j = threadIdx.x / GROUPS, c4 = threadIdx.x % GROUPS;
+  const long long cell0 = (long long)b * P + (long long)blk * S;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  auto rowsum = [&](int t) {                        // duplicates of a path in the batch: rare, summed in batch order
+    f32x4 sum = z;
+    for (; t >= 0; t = next[t]) sum += *reinterpret_cast<const f32x4*>(gout + (long long)t * Dout + c4 * 4);
+    return sum;
+  };
+  const int cpl = S / J;
+  for (int y = j * cpl; y < (j + 1) * cpl; ++y) {
+    f32x4 acc = z;
+    int e = bptr[cell0 + y], e1 = bptr[cell0 + y + 1];
+    for (; e + 4 <= e1; e += 4) {
       int k0 = bcode[e], k1 = bcode[e + 1], k2 = bcode[e + 2], k3 = bcode[e + 3];
       int t0 = first[k0 >= 0 ? k0 : -k0 - 1], t1 = first[k1 >= 0 ? k1 : -k1 - 1];
       int t2 = first[k2 >= 0 ? k2 : -k2 - 1], t3 = first[k3 >= 0 ? k3 : -k3 - 1];
@@ -174,30 +180,14 @@ __global__ void __launch_bounds__(256) masked_fc_bwd_runs_d_kernel(const int* __
       f32x4 sum = rowsum(first[code >= 0 ? code : -code - 1]);
       acc = code >= 0 ? acc + sum : acc - sum;
     }
-    *reinterpret_cast<f32x4*>(D + cell * Dout + c4 * 4) = acc;
+    *reinterpret_cast<f32x4*>(dl + y * Dout + c4 * 4) = acc;
   }
-}
-
-// Stage 2: suffix sums of D inside every block of S cells give dg[b][c] = d loss / d (f[b][c] * wT[c]);
-// dwT slab of design b: f * dg; df[b][c] = <dg, wT[c]> reduced over the channel groups of the cell (consecutive lanes).
-// GROUPS = Dout / 4 is a power of two <= 64 so that the reduction is a wave shuffle.
-template <int GROUPS>
-__global__ void __launch_bounds__(256) masked_fc_bwd_runs_scan_kernel(const float* __restrict__ D, const float* __restrict__ f,
-                                                                      const float* __restrict__ wT, float* __restrict__ dwT,
-                                                                      float* __restrict__ df, int B, int P, int S) {
-  constexpr int Dout = GROUPS * 4;
-  const int nblk = P / S;
-  const long long total = (long long)B * nblk * GROUPS;
-  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total) return;                                  // total is a multiple of GROUPS: whole lane groups exit
-  int c4 = (int)(t % GROUPS);
-  long long rest = t / GROUPS;
-  int blk = (int)(rest % nblk), b = (int)(rest / nblk);
-  const long long cell0 = (long long)b * P + (long long)blk * S;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  if (j != 0) return;
+  f32x4 acc = z;
   for (int y = S - 1; y >= 0; --y) {
     const long long cell = cell0 + y;
-    acc += *reinterpret_cast<const f32x4*>(D + cell * Dout + c4 * 4);
+    acc += *reinterpret_cast<const f32x4*>(dl + y * Dout + c4 * 4);
     f32x4 w = *reinterpret_cast<const f32x4*>(wT + ((long long)blk * S + y) * Dout + c4 * 4);
     *reinterpret_cast<f32x4*>(dwT + cell * Dout + c4 * 4) = acc * f[cell];
     float d = acc.x * w.x + acc.y * w.y + acc.z * w.z + acc.w * w.w;
@@ -414,7 +404,7 @@ int mmft_masked_fc_bwd(const int* csc_indptr, const int* csc_paths, const int* f
 }
 
 long long mmft_masked_fc_bwd_runs_workspace_bytes(int B, int P, int Dout) {
-  return (long long)(B > 1 ? 2 : 1) * B * P * Dout * 4;          // D, and per-design dwT slabs when B > 1
+  return B > 1 ? (long long)B * P * Dout * 4 : 0;                // per-design dwT slabs
 }
 
 int mmft_masked_fc_bwd_runs(const int* bnd_ptr, const int* bnd_code, const int* first, const int* next, const float* gout,
@@ -423,36 +413,32 @@ int mmft_masked_fc_bwd_runs(const int* bnd_ptr, const int* bnd_code, const int* 
   MMFT_REQUIRE(bnd_ptr && bnd_code && first && next && gout && f && wT && dwT && df, "masked_fc_bwd_runs: null pointer");
   const int groups = Dout / 4;
   MMFT_REQUIRE(B > 0 && P > 0 && S > 0 && P % S == 0 && Dout % 4 == 0 && groups >= 1 && groups <= 64 &&
-                   (groups & (groups - 1)) == 0,
-               "masked_fc_bwd_runs: Dout / 4 must be a power of two <= 64, P a multiple of the block size");
+                   (groups & (groups - 1)) == 0 && S % (256 / groups) == 0 && (long long)S * Dout * 4 <= 65536,
+               "masked_fc_bwd_runs: Dout / 4 must be a power of two <= 64, the block of S cells x Dout must fit 64 KB of "
+               "LDS and S be a multiple of 256 / (Dout / 4)");
   MMFT_REQUIRE(aligned16(gout) && aligned16(wT) && aligned16(dwT), "masked_fc_bwd_runs: 16-byte alignment");
-  MMFT_REQUIRE(workspace && workspace_bytes >= mmft_masked_fc_bwd_runs_workspace_bytes(B, P, Dout) && aligned16(workspace),
+  MMFT_REQUIRE(B == 1 || (workspace && workspace_bytes >= mmft_masked_fc_bwd_runs_workspace_bytes(B, P, Dout) &&
+                          aligned16(workspace)),
                "masked_fc_bwd_runs: workspace too small");
   DeviceGuard dg(device);
   hipStream_t st = (hipStream_t)stream;
-  const long long cells = (long long)B * P;
-  float* D = workspace;
-  float* slabs = B > 1 ? workspace + cells * Dout : dwT;
-  MMFT_LAUNCH("masked_fc_bwd_runs_d_kernel", 0.0, 0.0, masked_fc_bwd_runs_d_kernel, dim3(ew_grid(cells * groups)), dim3(256), st,
-              bnd_ptr, bnd_code, first, next, gout, D, cells, Dout);
-  int rc = check_launch("masked_fc_bwd_runs_d");
-  if (rc) return rc;
-  const long long total = (long long)B * (P / S) * groups;
-  const dim3 grid((unsigned)((total + 255) / 256));
-#define MMFT_SCAN(G)                                                                                                  \
-  MMFT_LAUNCH("masked_fc_bwd_runs_scan_kernel", 0.0, 4.0 * 3.0 * cells * Dout, masked_fc_bwd_runs_scan_kernel<G>, grid, \
-              dim3(256), st, D, f, wT, slabs, df, B, P, S)
+  float* slabs = B > 1 ? workspace : dwT;
+  const dim3 grid(P / S, B);
+  const size_t lds = (size_t)S * Dout * 4;
+#define MMFT_RUNS(G)                                                                                                   \
+  MMFT_LAUNCH_LDS("masked_fc_bwd_runs_kernel", 0.0, 0.0, masked_fc_bwd_runs_kernel<G>, grid, dim3(256), lds, st, bnd_ptr, \
+                  bnd_code, first, next, gout, f, wT, slabs, df, P, S)
   switch (groups) {
-    case 1: MMFT_SCAN(1); break;
-    case 2: MMFT_SCAN(2); break;
-    case 4: MMFT_SCAN(4); break;
-    case 8: MMFT_SCAN(8); break;
-    case 16: MMFT_SCAN(16); break;
-    case 32: MMFT_SCAN(32); break;
-    default: MMFT_SCAN(64); break;
+    case 1: MMFT_RUNS(1); break;
+    case 2: MMFT_RUNS(2); break;
+    case 4: MMFT_RUNS(4); break;
+    case 8: MMFT_RUNS(8); break;
+    case 16: MMFT_RUNS(16); break;
+    case 32: MMFT_RUNS(32); break;
+    default: MMFT_RUNS(64); break;
   }
-#undef MMFT_SCAN
-  rc = check_launch("masked_fc_bwd_runs_scan");
+#undef MMFT_RUNS
+  int rc = check_launch("masked_fc_bwd_runs");
   if (rc || B == 1) return rc;
   return launch_slab_reduce(slabs, B, (long long)P * Dout, dwT, 0, st);
 }
