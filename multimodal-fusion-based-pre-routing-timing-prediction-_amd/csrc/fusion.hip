@@ -113,11 +113,22 @@ __global__ void __launch_bounds__(256) masked_fc_fwd_runs_kernel(const int* __re
     int q = paths[t];
     const float* gb = GP + (long long)(foff ? foff[t] : 0) * Dout + c4 * 4;
     int r1 = run_ptr[q + 1];
-    for (int r = run_ptr[q] + j; r < r1; r += J) {
+    int r = run_ptr[q] + j;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (; r + J < r1; r += 2 * J) {                 // two runs per trip: their index -> row chains overlap
+      int s0 = run_start[r], e0 = s0 + run_len[r] - 1;
+      int s1 = run_start[r + J], e1 = s1 + run_len[r + J] - 1;
+      f32x4 h0 = *reinterpret_cast<const f32x4*>(gb + (long long)e0 * Dout);
+      f32x4 h1 = *reinterpret_cast<const f32x4*>(gb + (long long)e1 * Dout);
+      f32x4 l0 = (s0 % S) ? *reinterpret_cast<const f32x4*>(gb + (long long)(s0 - 1) * Dout) : z;
+      f32x4 l1 = (s1 % S) ? *reinterpret_cast<const f32x4*>(gb + (long long)(s1 - 1) * Dout) : z;
+      acc += h0 - l0;
+      acc += h1 - l1;
+    }
+    for (; r < r1; r += J) {
       int s = run_start[r], e = s + run_len[r] - 1;
       f32x4 hi = *reinterpret_cast<const f32x4*>(gb + (long long)e * Dout);
-      f32x4 lo = {0.f, 0.f, 0.f, 0.f};
-      if (s % S) lo = *reinterpret_cast<const f32x4*>(gb + (long long)(s - 1) * Dout);
+      f32x4 lo = (s % S) ? *reinterpret_cast<const f32x4*>(gb + (long long)(s - 1) * Dout) : z;
       acc += hi - lo;
     }
   }
