@@ -202,6 +202,12 @@ int mmft_pool2x2_bwd(const float* x, const float* gy, float* dx, int Nimg, int H
 int mmft_pixel_shuffle2(const float* in, const float* bias, float* out, int Nimg, int H, int W, int Co,
                         int device, void* stream);
 int mmft_pixel_unshuffle2(const float* in, float* out, int Nimg, int H, int W, int Co, int device, void* stream);
+/* the same two moves with the big tensor being a channel slice [c_off, c_off + Co) of an NHWC tensor with ldc channels:
+ * the up-sampled half of torch.cat([x2, x1], dim=1) (src/Unet.py:67) is written / read in place, no copy */
+int mmft_pixel_shuffle2_into(const float* in, const float* bias, float* out, int Nimg, int H, int W, int Co, int ldc,
+                             int c_off, int device, void* stream);
+int mmft_pixel_unshuffle2_from(const float* in, float* out, int Nimg, int H, int W, int Co, int ldc, int c_off, int device,
+                               void* stream);
 /* dst[n][y+y_off][x+x_off][c_off : c_off+Cs] = src[n][y][x][:]   (torch.cat + F.pad, src/Unet.py:59-67);
  * reverse=1 copies the same region from dst back into src (backward of cat/pad) */
 int mmft_copy_region_nhwc(float* src, int Nimg, int Hs, int Ws, int Cs, float* dst, int Hd, int Wd, int Cd,

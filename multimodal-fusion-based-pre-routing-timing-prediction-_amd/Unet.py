@@ -87,8 +87,7 @@ class Up(nn.Module):
         self.conv = DoubleConv(in_channels, out_channels)
 
     def forward(self, x1, x2):
-        x1 = C.conv_transpose2x2(x1, self.up.weight, self.up.bias)
-        return self.conv(C.cat_pad(x2, x1))
+        return self.conv(C.up_cat(x1, self.up.weight, self.up.bias, x2))
 
 
 class OutConv(nn.Module):

@@ -387,9 +387,9 @@ __global__ void __launch_bounds__(256) pool_bwd_kernel(const float* __restrict__
 // ------------------------------------------------------------------ pixel shuffle / region copy / layout
 __global__ void __launch_bounds__(256) pixel_shuffle_kernel(const float* __restrict__ in, const float* __restrict__ bias,
                                                             float* __restrict__ out, int Nimg, int H, int W, int Co,
-                                                            int reverse) {
-  // forward:  out[n][2y+a][2x+b][co] = in[n][y][x][(a*2+b)*Co+co] + bias[co]
-  // reverse:  out[n][y][x][(a*2+b)*Co+co] = in[n][2y+a][2x+b][co]
+                                                            int reverse, int ldc, int c_off) {
+  // forward:  out[n][2y+a][2x+b][c_off + co] = in[n][y][x][(a*2+b)*Co+co] + bias[co]     (big tensor: ldc channels)
+  // reverse:  out[n][y][x][(a*2+b)*Co+co] = in[n][2y+a][2x+b][c_off + co]
   long long total = (long long)Nimg * H * W * 4 * Co;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     int co = (int)(i % Co);
@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(256) pixel_shuffle_kernel(const float* __restr
     p /= W;
     int y = (int)(p % H);
     int n = (int)(p / H);
-    long long big = (((long long)n * 2 * H + 2 * y + (ab >> 1)) * 2 * W + 2 * x + (ab & 1)) * Co + co;
+    long long big = (((long long)n * 2 * H + 2 * y + (ab >> 1)) * 2 * W + 2 * x + (ab & 1)) * ldc + c_off + co;
     if (!reverse) out[big] = in[i] + (bias ? bias[co] : 0.f);
     else out[i] = in[big];
   }
@@ -597,21 +597,33 @@ int mmft_pool2x2_bwd(const float* x, const float* gy, float* dx, int Nimg, int H
   return check_launch("pool2x2_bwd");
 }
 
-int mmft_pixel_shuffle2(const float* in, const float* bias, float* out, int Nimg, int H, int W, int Co, int device,
-                        void* stream) {
+int mmft_pixel_shuffle2_into(const float* in, const float* bias, float* out, int Nimg, int H, int W, int Co, int ldc,
+                             int c_off, int device, void* stream) {
   MMFT_REQUIRE(in && out && Nimg > 0 && H > 0 && W > 0 && Co > 0, "pixel_shuffle2: bad args");
+  MMFT_REQUIRE(c_off >= 0 && ldc >= c_off + Co, "pixel_shuffle2: channel slice outside the destination");
   DeviceGuard dg(device);
   long long total = (long long)Nimg * H * W * 4 * Co;
-  MMFT_LAUNCH("pixel_shuffle_kernel", 0.0, 8.0 * total, pixel_shuffle_kernel, dim3(ew_grid(total)), dim3(256), (hipStream_t)stream, in, bias, out, Nimg, H, W, Co, 0);
+  MMFT_LAUNCH("pixel_shuffle_kernel", 0.0, 8.0 * total, pixel_shuffle_kernel, dim3(ew_grid(total)), dim3(256), (hipStream_t)stream, in, bias, out, Nimg, H, W, Co, 0, ldc, c_off);
   return check_launch("pixel_shuffle2");
 }
 
-int mmft_pixel_unshuffle2(const float* in, float* out, int Nimg, int H, int W, int Co, int device, void* stream) {
+int mmft_pixel_shuffle2(const float* in, const float* bias, float* out, int Nimg, int H, int W, int Co, int device,
+                        void* stream) {
+  return mmft_pixel_shuffle2_into(in, bias, out, Nimg, H, W, Co, Co, 0, device, stream);
+}
+
+int mmft_pixel_unshuffle2_from(const float* in, float* out, int Nimg, int H, int W, int Co, int ldc, int c_off, int device,
+                               void* stream) {
   MMFT_REQUIRE(in && out && Nimg > 0 && H > 0 && W > 0 && Co > 0, "pixel_unshuffle2: bad args");
+  MMFT_REQUIRE(c_off >= 0 && ldc >= c_off + Co, "pixel_unshuffle2: channel slice outside the source");
   DeviceGuard dg(device);
   long long total = (long long)Nimg * H * W * 4 * Co;
-  MMFT_LAUNCH("pixel_shuffle_kernel", 0.0, 8.0 * total, pixel_shuffle_kernel, dim3(ew_grid(total)), dim3(256), (hipStream_t)stream, in, nullptr, out, Nimg, H, W, Co, 1);
+  MMFT_LAUNCH("pixel_shuffle_kernel", 0.0, 8.0 * total, pixel_shuffle_kernel, dim3(ew_grid(total)), dim3(256), (hipStream_t)stream, in, nullptr, out, Nimg, H, W, Co, 1, ldc, c_off);
   return check_launch("pixel_unshuffle2");
+}
+
+int mmft_pixel_unshuffle2(const float* in, float* out, int Nimg, int H, int W, int Co, int device, void* stream) {
+  return mmft_pixel_unshuffle2_from(in, out, Nimg, H, W, Co, Co, 0, device, stream);
 }
 
 int mmft_copy_region_nhwc(float* src, int Nimg, int Hs, int Ws, int Cs, float* dst, int Hd, int Wd, int Cd, int c_off,

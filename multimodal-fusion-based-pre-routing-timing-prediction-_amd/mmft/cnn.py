@@ -184,6 +184,57 @@ def conv_transpose2x2(x, w, b):
     return ConvT2x2Fn.apply(x, w, b)
 
 
+class UpCatFn(torch.autograd.Function):
+    """torch.cat([x2, ConvTranspose2d(k=2, s=2)(x1)], dim=1) when no padding is needed (src/Unet.py:53-67, even
+    sizes): the transposed convolution's pixel shuffle writes straight into its channel slice of the concatenated
+    tensor and the backward reads the slice in place - the up-sampled half is never copied."""
+
+    @staticmethod
+    def forward(ctx, x1, w, b, x2):
+        xn, a = ops.to_nhwc(x1), ops.to_nhwc(x2)
+        N, Ci, H, W = xn.shape
+        Co, C2 = w.shape[1], a.shape[1]
+        t = ops.linear_fwd(ops.rows_view(xn), _wr(w), None)
+        out = ops.empty_nhwc(N, C2 + Co, 2 * H, 2 * W, a.device)
+        ops.copy_region(a, out, 0, 0, 0)
+        ops.pixel_shuffle2(t, b, N, H, W, Co, out=out, c_off=C2)
+        ctx.has_bias, ctx.C2 = b is not None, C2
+        ctx.sinks = (gradsink.of(w), gradsink.of(b))
+        ctx.save_for_backward(xn, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xn, w = ctx.saved_tensors
+        g = ops.to_nhwc(g)
+        N, Ci, H, W = xn.shape
+        Co, C2 = w.shape[1], ctx.C2
+        g2 = dx = dw = db = None
+        if ctx.needs_input_grad[3]:
+            g2 = ops.empty_nhwc(N, C2, 2 * H, 2 * W, g.device)
+            ops.copy_region(g2, g, 0, 0, 0, reverse=True)
+        gu = ops.pixel_unshuffle2(g, Co=Co, c_off=C2)      # [pixels, 4Co] from the slice, in place
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear_dgrad(gu, _wr(w)).reshape(N, H, W, Ci).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            sw = ctx.sinks[0] if w.permute(2, 3, 1, 0).is_contiguous() else None
+            dwr = gradsink.deliver(sw, lambda out: ops.linear_wgrad(gu, ops.rows_view(xn), dw=out), shape=(4 * Co, Ci))
+            dw = dwr.reshape(2, 2, Co, Ci).permute(3, 2, 0, 1) if dwr is not None else None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gs = ops.rows_view(g)[:, C2:]                  # strided column slice: colsum takes the row stride
+            db = gradsink.deliver(ctx.sinks[1], lambda out: ops.colsum(gs, out=out))
+        return dx, dw, db, g2
+
+
+def up_cat(x1, w, b, x2):
+    """cat([x2, conv_transpose2x2(x1)], 1); falls back to the two-step form when the sizes call for padding."""
+    if tuple(w.shape[2:]) != (2, 2):
+        raise NotImplementedError('only ConvTranspose2d(kernel_size=2, stride=2) is on the reference path')
+    if x2.shape[2] == 2 * x1.shape[2] and x2.shape[3] == 2 * x1.shape[3] and x2.shape[1] % 4 == 0:
+        return UpCatFn.apply(x1, w, b, x2)
+    return cat_pad(x2, conv_transpose2x2(x1, w, b))
+
+
 class CatPadFn(torch.autograd.Function):
     """torch.cat([x2, F.pad(x1, centre)], dim=1)  (src/Unet.py:59-67)."""
 

@@ -507,25 +507,33 @@ def pool2x2_bwd(x, gy, mode):
     return dx
 
 
-def pixel_shuffle2(t, bias, N, H, W, Co):
-    """t: [N*H*W, 4*Co] rows -> (N,Co,2H,2W) channels_last, + bias[co]."""
+def pixel_shuffle2(t, bias, N, H, W, Co, out=None, c_off=0):
+    """t: [N*H*W, 4*Co] rows -> (N,Co,2H,2W) channels_last, + bias[co]; with `out` given: into its channel slice
+    [c_off, c_off + Co)."""
     _rows2d(t, 't')
     if t.shape != (N * H * W, 4 * Co) or not t.is_contiguous():
         raise ValueError('pixel_shuffle2: bad input shape')
-    out = empty_nhwc(N, Co, 2 * H, 2 * W, t.device)
+    if out is None:
+        out = empty_nhwc(N, Co, 2 * H, 2 * W, t.device)
+    _nhwc(out, 'out')
+    if out.shape[0] != N or tuple(out.shape[2:]) != (2 * H, 2 * W) or c_off < 0 or c_off + Co > out.shape[1]:
+        raise ValueError('pixel_shuffle2: destination shape')
     dev, st = lib.stream_args(t)
-    lib.call('mmft_pixel_shuffle2', t, bias, out, N, H, W, Co, dev, st)
+    lib.call('mmft_pixel_shuffle2_into', t, bias, out, N, H, W, Co, out.shape[1], int(c_off), dev, st)
     return out
 
 
-def pixel_unshuffle2(g):
-    """(N,Co,2H,2W) channels_last -> [N*H*W, 4*Co] rows."""
+def pixel_unshuffle2(g, Co=None, c_off=0):
+    """(N,C,2H,2W) channels_last, channel slice [c_off, c_off + Co) (default: all) -> [N*H*W, 4*Co] rows."""
     _nhwc(g, 'g')
-    N, Co, H2, W2 = g.shape
+    N, C, H2, W2 = g.shape
+    Co = C if Co is None else Co
+    if c_off < 0 or c_off + Co > C:
+        raise ValueError('pixel_unshuffle2: channel slice')
     H, W = H2 // 2, W2 // 2
     out = torch.empty((N * H * W, 4 * Co), dtype=torch.float32, device=g.device)
     dev, st = lib.stream_args(g)
-    lib.call('mmft_pixel_unshuffle2', g, out, N, H, W, Co, dev, st)
+    lib.call('mmft_pixel_unshuffle2_from', g, out, N, H, W, Co, C, int(c_off), dev, st)
     return out
 
 
