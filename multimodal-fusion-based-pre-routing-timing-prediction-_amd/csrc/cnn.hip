@@ -468,6 +468,8 @@ int mmft_conv2d_dgrad(const float* dy, const float* w, float* dx, int Nimg, int 
   MMFT_REQUIRE(workspace && workspace_bytes >= need, "conv2d_dgrad: workspace too small");
   DeviceGuard dg(device);
   hipStream_t st = (hipStream_t)stream;
+  if (conv_direct_ok(dy, w, nullptr, dx, W, Co, Ci, KH, KW, pad))      // narrow layers: the kernel flips w while staging it
+    return conv_direct_launch(dy, w, nullptr, dx, Nimg, H, W, Co, Ci, ACT_NONE, 0.f, st, 1);
   hipLaunchKernelGGL(dgrad_weight_kernel, dim3(ew_grid(need / 4)), dim3(256), 0, st, w, workspace, Co, KH, KW, Ci);
   int rc = check_launch("dgrad_weight");
   if (rc) return rc;

@@ -23,6 +23,7 @@ struct ConvDirectArgs {
   int N, H, W;
   int act;
   float slope;
+  int flip;            // 1: input-gradient use - w is the FORWARD weight [CI][3][3][CO] of the layer, read flipped
 };
 
 template <int CI, int CO>
@@ -31,9 +32,19 @@ __global__ void __launch_bounds__(256) conv3x3_direct_kernel(ConvDirectArgs a) {
   constexpr int NS = 4, CC = CI / 16, CS = CO / 16, STAGES = 3 * CC;
   extern __shared__ __attribute__((aligned(16))) float wl0[];      // [CO][WS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int e = tid; e < CO * K / 4; e += 256) {
-    int co = e / (K / 4), k4 = e % (K / 4);
-    *reinterpret_cast<f32x4*>(wl0 + co * WS + k4 * 4) = *reinterpret_cast<const f32x4*>(a.w + (long long)co * K + k4 * 4);
+  if (!a.flip) {
+    for (int e = tid; e < CO * K / 4; e += 256) {
+      int co = e / (K / 4), k4 = e % (K / 4);
+      *reinterpret_cast<f32x4*>(wl0 + co * WS + k4 * 4) = *reinterpret_cast<const f32x4*>(a.w + (long long)co * K + k4 * 4);
+    }
+  } else {
+    // dx = conv(dy, w') with w'[co][tap][ci] = w[ci][8 - tap][co]: the 180-degree flip and the channel transpose are
+    // done while staging (<= 37 KB once per persistent workgroup) instead of by a re-layout kernel per step
+    for (int e = tid; e < CO * K; e += 256) {
+      int co = e / K, k = e % K;
+      int tap = k / CI, ci = k % CI;
+      wl0[co * WS + k] = a.w[((long long)ci * 9 + (8 - tap)) * CO + co];
+    }
   }
   __syncthreads();
   const int r = lane & 15, q = lane >> 4;
@@ -148,8 +159,8 @@ inline void conv_direct_launch_t(const ConvDirectArgs& a, hipStream_t st) {
 }
 
 inline int conv_direct_launch(const float* x, const float* w, const float* bias, float* y, int Nimg, int H, int W, int Ci,
-                              int Co, int act, float slope, hipStream_t st) {
-  ConvDirectArgs a{x, w, bias, y, Nimg, H, W, act, slope};
+                              int Co, int act, float slope, hipStream_t st, int flip = 0) {
+  ConvDirectArgs a{x, w, bias, y, Nimg, H, W, act, slope, flip};
   if (Ci == 16 && Co == 16) conv_direct_launch_t<16, 16>(a, st);
   else if (Ci == 16 && Co == 32) conv_direct_launch_t<16, 32>(a, st);
   else if (Ci == 32 && Co == 16) conv_direct_launch_t<32, 16>(a, st);

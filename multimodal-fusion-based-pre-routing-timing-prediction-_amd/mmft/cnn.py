@@ -142,6 +142,33 @@ def _wr(w):
     return v.reshape(-1, w.shape[0])
 
 
+def _convt_param_grads(ctx, gu, xn, w, Co, Ci, g_rows):
+    """(dw, db) of ConvTranspose2d(k=2, s=2) from the unshuffled gradient gu [pixels, (a,b,co)]: dw is the GEMM
+    gu^T x; the bias gradient is the GEMM's column-sum by-product folded over the four (a,b) positions, so the
+    gradient image is not read a second time.  Entries taken by a gradient sink come back as None."""
+    want_w = ctx.needs_input_grad[1]
+    want_b = ctx.has_bias and ctx.needs_input_grad[2]
+    # the sink is usable when the parameter is stored in (a,b,co,ci) order (Unet.Up keeps it that way)
+    sw = ctx.sinks[0] if w.permute(2, 3, 1, 0).is_contiguous() else None
+    dw = db = None
+    if want_w and want_b:
+        col = {}
+
+        def both(out):
+            dwr, col['s'] = ops.linear_wgrad(gu, ops.rows_view(xn), dw=out, with_bias=True)     # [(a,b,co)][ci], [4Co]
+            return dwr
+        dwr = gradsink.deliver(sw, both, shape=(4 * Co, Ci))
+        dw = dwr.reshape(2, 2, Co, Ci).permute(3, 2, 0, 1) if dwr is not None else None
+        db = gradsink.deliver(ctx.sinks[1], lambda out: torch.sum(col['s'].view(4, Co), 0, out=out)
+                              if out is not None else col['s'].view(4, Co).sum(0))
+    elif want_w:
+        dwr = gradsink.deliver(sw, lambda out: ops.linear_wgrad(gu, ops.rows_view(xn), dw=out), shape=(4 * Co, Ci))
+        dw = dwr.reshape(2, 2, Co, Ci).permute(3, 2, 0, 1) if dwr is not None else None
+    elif want_b:
+        db = gradsink.deliver(ctx.sinks[1], lambda out: ops.colsum(g_rows(), out=out))
+    return dw, db
+
+
 class ConvT2x2Fn(torch.autograd.Function):
     """ConvTranspose2d(k=2, s=2) with bias  (src/Unet.py:53) = GEMM [pixels x Ci][Ci x 4Co] + pixel shuffle."""
 
@@ -167,14 +194,7 @@ class ConvT2x2Fn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = ops.linear_dgrad(gu, _wr(w)).reshape(N, H, W, Ci).permute(0, 3, 1, 2)
-        if ctx.needs_input_grad[1]:
-            # the sink is usable when the parameter is stored in (a,b,co,ci) order (Unet.Up keeps it that way)
-            sw = ctx.sinks[0] if w.permute(2, 3, 1, 0).is_contiguous() else None
-            dwr = gradsink.deliver(sw, lambda out: ops.linear_wgrad(gu, ops.rows_view(xn), dw=out),
-                                   shape=(4 * Co, Ci))                                            # [(a,b,co)][ci]
-            dw = dwr.reshape(2, 2, Co, Ci).permute(3, 2, 0, 1) if dwr is not None else None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = gradsink.deliver(ctx.sinks[1], lambda out: ops.colsum(ops.rows_view(g), out=out))
+        dw, db = _convt_param_grads(ctx, gu, xn, w, Co, Ci, lambda: ops.rows_view(g))
         return dx, dw, db
 
 
@@ -216,13 +236,7 @@ class UpCatFn(torch.autograd.Function):
         gu = ops.pixel_unshuffle2(g, Co=Co, c_off=C2)      # [pixels, 4Co] from the slice, in place
         if ctx.needs_input_grad[0]:
             dx = ops.linear_dgrad(gu, _wr(w)).reshape(N, H, W, Ci).permute(0, 3, 1, 2)
-        if ctx.needs_input_grad[1]:
-            sw = ctx.sinks[0] if w.permute(2, 3, 1, 0).is_contiguous() else None
-            dwr = gradsink.deliver(sw, lambda out: ops.linear_wgrad(gu, ops.rows_view(xn), dw=out), shape=(4 * Co, Ci))
-            dw = dwr.reshape(2, 2, Co, Ci).permute(3, 2, 0, 1) if dwr is not None else None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gs = ops.rows_view(g)[:, C2:]                  # strided column slice: colsum takes the row stride
-            db = gradsink.deliver(ctx.sinks[1], lambda out: ops.colsum(gs, out=out))
+        dw, db = _convt_param_grads(ctx, gu, xn, w, Co, Ci, lambda: ops.rows_view(g)[:, C2:])
         return dx, dw, db, g2
 
 
