@@ -638,6 +638,16 @@ inline void launch_cfg(const XL& xl, const WL& wl, const Epi& epi, int M, int N,
   MMFT_LAUNCH((gemm_kernel_name<CFG, XL, WL>()), 2.0 * M * N * K, alg_bytes, (gemm_f32_kernel<CFG, XL, WL>), grid, dim3(256), st, xl, wl, epi, M, N, K, ksplit);
 }
 
+// K up to which short GEMMs (few output tiles) take the 64-deep K step; MMFT_GEMM_DEEPK_LIMIT overrides (tuning)
+inline int gemm_deepk_limit() {
+  static int lim = -1;
+  if (lim < 0) {
+    const char* e = getenv("MMFT_GEMM_DEEPK_LIMIT");
+    lim = e ? atoi(e) : 1280;      // 3x3 convolutions with up to 128 input channels (K = 1152) included
+  }
+  return lim;
+}
+
 // number of split-K slabs launch_gemm will actually use for a requested count
 inline int effective_splits(int K, int splits) {
   if (splits <= 1) return 1;
@@ -687,7 +697,7 @@ inline int launch_gemm(const XL& xl, const WL& wl, const Epi& epi, int M, int N,
   // Short level-serial GEMMs (few rows, K <= 512): a 16-deep K step costs one global round trip (~1 us) for 4-16
   // MFMAs, so the tile's K loop is latency-bound.  BK = 64 makes a quarter of the round trips with four times the
   // bytes in flight per thread.
-  if (splits <= 1 && K >= 64 && K <= 512 && (long long)M * N <= (1ll << 23) && ncap >= 64 && mcap >= 32) {
+  if (splits <= 1 && K >= 64 && K <= gemm_deepk_limit() && (long long)M * N <= (1ll << 23) && ncap >= 64 && mcap >= 32) {
     launch_cfg<TileCfg<32, 64, 64, 2, 2>>(xl, wl, epi, M, N, K, splits, st);
     return check_launch("gemm_f32");
   }
