@@ -134,13 +134,19 @@ int mmft_seg_mean_fwd(const float* src, long long lds, const int* in_indptr, con
  *   gh = G[v] + sum_{e: v->w in out_net(v)} G[w] * out_net_weight[e]
  *             + sum_{w in out_cell(v)} DA[w] * exp(h[v]-LSE[w]) * (1 + h[v] - A[w])
  *   G[v] = relu ? (h[v] > 0 ? gh : 0) : gh
- * G rows of later levels hold d(loss)/d(pre-activation), DA rows d(loss)/d(A); both must be zero for
- * nodes whose backward has not run. */
+ * G rows of later levels hold d(loss)/d(pre-activation), DA rows d(loss)/d(A). */
 int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows, int row0, int n, int D,
                         const int* out_net_indptr, const int* out_net_indices, const float* out_net_weight,
                         const int* out_cell_indptr, const int* out_cell_indices,
-                        const float* A, const float* LSE, const float* DA, int relu, long long alg_bytes,
-                        int device, void* stream);
+                        const float* A, const float* LSE, const float* DA, int relu, const unsigned char* own_mask,
+                        long long alg_bytes, int device, void* stream);
+/* own_mask (may be NULL): per-node flag telling whether G[v] already holds a gradient of its own (a sampled endpoint,
+ * src/model.py:213); rows without the flag start from zero, so G needs no 4*N*D-byte fill per step.
+ * mmft_target_rows_begin zeroes the G rows of the endpoints idx[0..n) and sets their flags (the scatter-add of the
+ * endpoint gradients follows), mmft_target_rows_end clears the flags after the reverse sweep. */
+int mmft_target_rows_begin(float* G, long long ld, const int* idx, int n, int D, unsigned char* flags, int device,
+                           void* stream);
+int mmft_target_rows_end(const int* idx, int n, unsigned char* flags, int device, void* stream);
 /* Persistent forward sweep: ONE launch for levels 1..L-1 of a mini-batch (the L per-level PathConv.forward calls of
  * src/train.py:490-511).  h must hold the *_self MLP outputs of every node (level 0 already activated); levels
  * are separated by an in-kernel grid barrier (agent-scope release/acquire, bounded spin).  level_ptr[L+1] /

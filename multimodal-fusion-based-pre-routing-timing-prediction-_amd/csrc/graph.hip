@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
     float* __restrict__ G, const float* __restrict__ h, long long ld, const int* __restrict__ rows, int row0, int n,
     int D, const int* __restrict__ on_ptr, const int* __restrict__ on_idx, const float* __restrict__ on_w,
     const int* __restrict__ oc_ptr, const int* __restrict__ oc_idx, const float* __restrict__ A,
-    const float* __restrict__ LSE, const float* __restrict__ DA, int relu) {
+    const float* __restrict__ LSE, const float* __restrict__ DA, int relu, const unsigned char* __restrict__ own) {
   MMFT_NODE_LOOP(n, D) {
     int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
     int v = rows ? rows[i] : row0 + i;
@@ -99,7 +99,8 @@ __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
     int e = on_ptr[v], e1 = on_ptr[v + 1];
     const int c0 = oc_ptr[v], c1 = oc_ptr[v + 1];
     f32x4 hv = ld4(h + off);
-    f32x4 g = ld4(G + off);
+    // own-row gradient: present only where a sampled endpoint put one (own == NULL: G was zero-filled by the caller)
+    f32x4 g = (!own || own[v]) ? ld4(G + off) : f32x4{0.f, 0.f, 0.f, 0.f};
     // net consumers: d/dh[v] of the mean over the consumer's in-edges (weight = 1/indeg, per out-edge, static).
     // Four edges are issued together so that the dependent index -> row loads of different edges overlap.
     for (; e + 4 <= e1; e += 4) {
@@ -137,6 +138,18 @@ __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
       for (int j = 0; j < 4; ++j) g[j] = hv[j] > 0.f ? g[j] : 0.f;
     }
     st4(G + off, g);
+  }
+}
+
+// value = 1: zero the G rows of the sampled endpoints and flag them (the scatter-add of their gradients follows);
+// value = 0: clear the flags again.  Duplicated endpoints write the same values.
+__global__ void __launch_bounds__(256) target_rows_kernel(float* __restrict__ G, long long ld, const int* __restrict__ idx,
+                                                          int n, int D, unsigned char* __restrict__ flags, int value) {
+  MMFT_NODE_LOOP(n, D) {
+    int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
+    int v = idx[i];
+    if (G) st4(G + (long long)v * ld + c, f32x4{0.f, 0.f, 0.f, 0.f});
+    if (c == 0) flags[v] = (unsigned char)value;
   }
 }
 
@@ -228,7 +241,8 @@ int mmft_seg_sum_fwd(const float* src, long long lds, const int* indptr, const i
 int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows, int row0, int n, int D,
                         const int* out_net_indptr, const int* out_net_indices, const float* out_net_weight,
                         const int* out_cell_indptr, const int* out_cell_indices, const float* A, const float* LSE,
-                        const float* DA, int relu, long long alg_bytes, int device, void* stream) {
+                        const float* DA, int relu, const unsigned char* own_mask, long long alg_bytes, int device,
+                        void* stream) {
   CHECK_ROWS("level_bwd_pull");
   MMFT_REQUIRE(G && h && out_net_indptr && out_cell_indptr && A && LSE && DA,
                "level_bwd_pull: null pointer");
@@ -239,8 +253,27 @@ int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows,
   DeviceGuard dg(device);
   MMFT_LAUNCH("level_bwd_pull_kernel", 0.0, alg_bytes > 0 ? (double)alg_bytes : 3.0 * 4.0 * n * D, level_bwd_pull_kernel,
               dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, G, h, ld, rows, row0, n, D, out_net_indptr,
-              out_net_indices, out_net_weight, out_cell_indptr, out_cell_indices, A, LSE, DA, relu);
+              out_net_indices, out_net_weight, out_cell_indptr, out_cell_indices, A, LSE, DA, relu, own_mask);
   return check_launch("level_bwd_pull");
+}
+
+int mmft_target_rows_begin(float* G, long long ld, const int* idx, int n, int D, unsigned char* flags, int device,
+                           void* stream) {
+  CHECK_ROWS("target_rows_begin");
+  if (n == 0) return MMFT_OK;
+  MMFT_REQUIRE(G && idx && flags && ld >= D && ld % 4 == 0 && aligned16(G), "target_rows_begin: bad arguments");
+  DeviceGuard dg(device);
+  hipLaunchKernelGGL(target_rows_kernel, dim3(node_grid(n, D)), dim3(256), 0, (hipStream_t)stream, G, ld, idx, n, D, flags, 1);
+  return check_launch("target_rows_begin");
+}
+
+int mmft_target_rows_end(const int* idx, int n, unsigned char* flags, int device, void* stream) {
+  MMFT_REQUIRE(n >= 0, "target_rows_end: negative count");
+  if (n == 0) return MMFT_OK;
+  MMFT_REQUIRE(idx && flags, "target_rows_end: null pointer");
+  DeviceGuard dg(device);
+  hipLaunchKernelGGL(target_rows_kernel, dim3(node_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, nullptr, 0, idx, n, 4, flags, 0);
+  return check_launch("target_rows_end");
 }
 
 int mmft_gather_rows(const float* src, long long lds, const int* idx, int n, int D, float* dst, long long ldd,

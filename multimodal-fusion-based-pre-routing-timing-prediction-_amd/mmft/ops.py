@@ -318,7 +318,22 @@ def scatter_add_rows_det(dst, idx, src):
     return dst
 
 
-def level_bwd_pull(G, h, rows, out_net, out_net_w, out_cell, A, LSE, DA, relu=True, alg_bytes=0):
+def target_rows_begin(G, idx, flags):
+    """Zero the rows idx of G and flag them (uint8 per node) ahead of the endpoint-gradient scatter."""
+    _rows2d(G, 'G'); _idx(idx, 'idx'); _chk(flags, 'flags', torch.uint8)
+    if flags.numel() != G.shape[0]:
+        raise ValueError('target_rows_begin: one flag per node expected')
+    dev, st = lib.stream_args(G)
+    lib.call('mmft_target_rows_begin', G, G.stride(0), idx, idx.numel(), G.shape[1], flags, dev, st)
+
+
+def target_rows_end(idx, flags):
+    _idx(idx, 'idx'); _chk(flags, 'flags', torch.uint8)
+    dev, st = lib.stream_args(flags)
+    lib.call('mmft_target_rows_end', idx, idx.numel(), flags, dev, st)
+
+
+def level_bwd_pull(G, h, rows, out_net, out_net_w, out_cell, A, LSE, DA, relu=True, alg_bytes=0, own=None):
     for t, nm in ((G, 'G'), (h, 'h'), (A, 'A'), (LSE, 'LSE'), (DA, 'DA')):
         _rows2d(t, nm)
         if t.shape != h.shape or t.stride(0) != h.stride(0):
@@ -329,9 +344,13 @@ def level_bwd_pull(G, h, rows, out_net, out_net_w, out_cell, A, LSE, DA, relu=Tr
     if out_net_w.numel() != out_net[1].numel() or not out_net_w.is_contiguous():
         raise ValueError('level_bwd_pull: one weight per out-net edge expected')
     rt, row0, n = _rowspec(rows, N, 'rows')
+    if own is not None:
+        _chk(own, 'own', torch.uint8)
+        if own.numel() != N:
+            raise ValueError('level_bwd_pull: one own-gradient flag per node expected')
     dev, st = lib.stream_args(h)
     lib.call('mmft_level_bwd_pull', G, h, h.stride(0), rt, row0, n, h.shape[1], out_net[0], out_net[1], out_net_w,
-             out_cell[0], out_cell[1], A, LSE, DA, int(relu), int(alg_bytes), dev, st)
+             out_cell[0], out_cell[1], A, LSE, DA, int(relu), own, int(alg_bytes), dev, st)
     return G
 
 

@@ -49,7 +49,7 @@ class SweepState:
         self.LSE = self._buf('LSE', self.D)
         self.HS = self._buf('HS', self.Hd)
         self.HN = self._buf('HN', self.Hd)
-        self.G = self.DA = self.DHN = None
+        self.G = self.DA = self.DHN = self.tflag = None
         self.level_meta = None      # per-level static facts (contiguous range, algorithmic bytes), whole-sweep entry
         self.levels = []            # (level_id, rows) in forward order
         self.token = None
@@ -63,7 +63,7 @@ class SweepState:
             self._bufs[name] = b
         return b
 
-    def begin_backward(self, zero_da=True):
+    def begin_backward(self, zero_da=True, zero_g=True):
         """zero_da=False (whole-sweep entry): every DA row the reverse pull reads belongs to a cell node of a level >= 2,
         and the reverse sweep writes that row (fc_cell_neigh's input gradient) before any lower level pulls from it,
         so the 268 MB fill per step is skipped; the per-level drop-in form keeps it (a caller may stop a sweep early)."""
@@ -74,7 +74,14 @@ class SweepState:
                 self.DA = self._buf('DA', self.D)
                 if fresh:
                     self.DA.zero_()
-            self.G.zero_()
+            if zero_g:
+                self.G.zero_()
+            else:
+                # whole-sweep entry: only the sampled endpoints start with a gradient of their own; the reverse pull
+                # takes zero for every other row (flag per node), so the 268 MB fill of G per step is skipped too
+                if 'tflag' not in self._bufs:
+                    self._bufs['tflag'] = torch.zeros(self.N, dtype=torch.uint8, device=self.h.device)
+                self.tflag = self._bufs['tflag']
             if zero_da:
                 self.DA.zero_()
             self.bwd_active = True
@@ -368,8 +375,9 @@ class SweepFn(torch.autograd.Function):
     def backward(ctx, gout):
         st, g = ctx.state, ctx.state.graph
         st.bwd_active = False
-        st.begin_backward(zero_da=False)
+        st.begin_backward(zero_da=False, zero_g=False)
         if ctx.tix.numel():
+            ops.target_rows_begin(st.G, ctx.tix, st.tflag)
             ops.scatter_add_rows(st.G, ctx.tix, gout if gout.is_contiguous() else gout.contiguous())
         P = [_w(p) for p in st.params]
         w1g, w2g = P[8], P[10]
@@ -380,10 +388,12 @@ class SweepFn(torch.autograd.Function):
             meta = st.level_meta[level_id] if st.level_meta else None
             spec = meta['range'] if (meta and meta['range']) else rows
             ops.level_bwd_pull(st.G, st.h, spec, out_net, in_net_ptr, out_cell, st.A, st.LSE, st.DA, relu=st.relu,
-                               alg_bytes=meta['bytes_pull'] if meta else 0)
+                               alg_bytes=meta['bytes_pull'] if meta else 0, own=st.tflag)
             if level_id % 2 == 0 and level_id > 0:
                 _cell_neigh_bwd(st, rows, w1g, w2g, keep_dhn=True)
         grads = _batched_param_grads(st, P, dhn_ready=True) if ctx.nparams else []
+        if ctx.tix.numel():
+            ops.target_rows_end(ctx.tix, st.tflag)
         st.bwd_active = False
         return (None, None, None, *grads)
 
