@@ -155,7 +155,9 @@ class TrainStep:
     def forward(self, path_ids_per_design, _sel=None):
         b, g = self.batch, self.batch.graph
         ends_d, paths_d, foff_d, counts, ends_h, lv_d = _sel if _sel is not None else b.select(path_ids_per_design)
-        self.h.zero_()                                                                    # src/train.py:342,559
+        if self.mode != 'sweep':
+            self.h.zero_()                                                                # src/train.py:342,559
+        # (whole-sweep entry: the *_self MLPs store every level node's row before anything reads it - no 268 MB fill)
         g.ndata['h'] = self.h
         if self.mode == 'sweep':
             # The netlist sweep and the U-Net are independent until the fusion head: the level-serial sweep
