@@ -320,11 +320,16 @@ static int wgrad_impl(const float* g, const int* gidx, long long ldg, const floa
   long long need = (long long)splits * ((long long)out * in + (db ? out : 0)) * 4;
   MMFT_REQUIRE(workspace && workspace_bytes >= need, "linear_wgrad: workspace too small (%lld < %lld)", workspace_bytes,
                need);
-  float* cs_slabs = db ? workspace + (long long)splits * out * in : nullptr;
-  Epi epi{workspace, in, nullptr, nullptr, nullptr, nullptr, 0, EPI_STORE, ACT_NONE, 0.f, (long long)out * in,
-          (in % 4 == 0) && aligned16(workspace), cs_slabs, out, 0};
+  // db right behind dw (weight and bias of a Linear are neighbours in the flat gradient buffer): the column-sum
+  // slab rides at the tail of each weight slab and ONE reduction launch finishes both
+  const bool joined = db && db == dw + (long long)out * in && ((long long)out * in) % 4 == 0 && out % 4 == 0;
+  const long long wslab = (long long)out * in + (joined ? out : 0);
+  float* cs_slabs = !db ? nullptr : (joined ? workspace + (long long)out * in : workspace + (long long)splits * out * in);
+  Epi epi{workspace, in, nullptr, nullptr, nullptr, nullptr, 0, EPI_STORE, ACT_NONE, 0.f, wslab,
+          (in % 4 == 0) && aligned16(workspace), cs_slabs, joined ? wslab : (long long)out, 0};
   int rc = launch_gemm(xl, wl, epi, out, in, rows, splits, st);
   if (rc) return rc;
+  if (joined) return launch_slab_reduce(workspace, splits, wslab, dw, accumulate, st);
   rc = launch_slab_reduce(workspace, splits, (long long)out * in, dw, accumulate, st);
   if (rc || !db) return rc;
   return launch_slab_reduce(cs_slabs, splits, out, db, accumulate, st);

@@ -37,8 +37,9 @@ struct MlpGradArgs {
   int row0, n, fin;
   const float* w2;
   long long ldw2;
-  float* slab_w;    // [2 * grid][HD][fin]
-  float* slab_b;    // [2 * grid][HD]
+  float* slab_w;    // [2 * grid] slabs of [HD][fin], `wstride` floats apart
+  float* slab_b;    // [2 * grid] slabs of [HD], `bstride` floats apart (interleaved with slab_w when dw1 | db1 are neighbours)
+  long long wstride, bstride;
 };
 
 template <int FT>   // input-feature subtiles of 16 (fin <= 16 * FT)
@@ -168,7 +169,7 @@ __global__ void __launch_bounds__(MG_WAVES * 64, 1) mlp_first_layer_grads_kernel
 
   // ---- partial results of this quad: dW1[hidden][feature] (lane: features 4q..4q+3 of hidden column lane&15)
   const int z = blockIdx.x * 2 + quad;
-  float* sw = a.slab_w + (long long)z * MG_HD * a.fin;
+  float* sw = a.slab_w + (long long)z * a.wstride;
 #pragma unroll
   for (int f = 0; f < FT; ++f)
 #pragma unroll
@@ -180,7 +181,7 @@ __global__ void __launch_bounds__(MG_WAVES * 64, 1) mlp_first_layer_grads_kernel
         if (feat < a.fin) sw[(long long)hcol * a.fin + feat] = acc2[f][j][t];
       }
     }
-  float* sb = a.slab_b + (long long)z * MG_HD;
+  float* sb = a.slab_b + (long long)z * a.bstride;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float v = cs[j];                                     // rows 4q..4q+3 of every block: sum the four quarters
@@ -228,9 +229,12 @@ extern "C" int mmft_mlp2_first_layer_grads(const float* g, long long ldg, const 
   long long need = mmft_mlp2_first_layer_grads_workspace_bytes(fin, HD);
   MMFT_REQUIRE(workspace && workspace_bytes >= need, "mlp2_first_layer_grads: workspace too small (%lld < %lld)",
                workspace_bytes, need);
+  // db1 right behind dw1 (neighbours in the flat gradient buffer): interleave the slabs and reduce both in one launch
+  const bool joined = db1 == dw1 + (long long)HD * fin && ((long long)HD * fin) % 4 == 0;
+  const long long wslab = (long long)HD * fin + (joined ? HD : 0);
   float* slab_w = workspace;
-  float* slab_b = workspace + (long long)2 * grid * HD * fin;
-  MlpGradArgs a{g, ldg, hid, ldh, x, ldx, rows, row0, n, fin, w2, ldw2, slab_w, slab_b};
+  float* slab_b = joined ? workspace + (long long)HD * fin : workspace + (long long)2 * grid * HD * fin;
+  MlpGradArgs a{g, ldg, hid, ldh, x, ldx, rows, row0, n, fin, w2, ldw2, slab_w, slab_b, wslab, joined ? wslab : (long long)HD};
   const size_t lds = (size_t)MG_HD * MG_WS * 4;
   const int ft = (fin + 15) / 16;
   static bool attr_done[4] = {false, false, false, false};
@@ -254,6 +258,7 @@ extern "C" int mmft_mlp2_first_layer_grads(const float* g, long long ldg, const 
   }
   int rc = check_launch("mlp2_first_layer_grads");
   if (rc) return rc;
+  if (joined) return launch_slab_reduce(slab_w, 2 * grid, wslab, dw1, accumulate, st);
   rc = launch_slab_reduce(slab_w, 2 * grid, (long long)HD * fin, dw1, accumulate, st);
   if (rc) return rc;
   return launch_slab_reduce(slab_b, 2 * grid, HD, db1, accumulate, st);
