@@ -9,12 +9,16 @@
 // th.nn.Linear calls inside PathConv.apply_cell_func (reference src/model.py:138-146) and its autograd mirror.
 // Same fp32 MFMA fragments, LDS strides and k permutation as gemm_engine.h; 128 -> 256 -> 128 widths only
 // (the reference's PathConv defaults, src/model.py:48-51); other widths use the two-launch path.
+// 8 waves per workgroup (two per SIMD): a level is one round of <= 256 workgroups, so its duration is one workgroup's
+// latency; halving every wave's share of the MFMAs and of the register-resident weight panels took 24 -> 19 us
+// (MMFT_MLP2_WAVES=4 restores the four-wave form for comparison).
 #include "mlp2_core.h"
 
 namespace mmft {
 
-template <bool KM>
-__global__ void __launch_bounds__(256, 1) mlp2_rows_kernel(Mlp2Args a) {
+template <bool KM, int NW>      // NW waves per workgroup: each owns 256 / NW hidden columns and 128 / NW output columns
+__global__ void __launch_bounds__(NW * 64, 1) mlp2_rows_kernel(Mlp2Args a) {
+  constexpr int NT = NW * 64, HC = (M2_HD / 16) / NW, OC = (M2_D2 / 16) / NW;
   constexpr int XS = M2_K1 + 8;                       // 136: x1 tile, whole K resident
   constexpr int HS = M2_HD + 8;                       // 264: hidden tile
   constexpr int W1S = KM ? (M2_HD + 4) : (M2_BK + 8);
@@ -31,40 +35,40 @@ __global__ void __launch_bounds__(256, 1) mlp2_rows_kernel(Mlp2Args a) {
   const int m0 = blockIdx.x * M2_BM;
 
   // ---- every global load of the kernel is issued here: both weight panels and the gathered x1 rows
-  WPanel<KM, M2_HD, M2_K1 / M2_BK> p1;
-  WPanel<KM, M2_D2, M2_HD / M2_BK> p2;
+  WPanel<KM, M2_HD, M2_K1 / M2_BK, NT> p1;
+  WPanel<KM, M2_D2, M2_HD / M2_BK, NT> p2;
   p1.load(a.w1, a.ldw1, tid);
-  f32x4 xr[M2_BM * M2_K1 / 4 / 256];
+  f32x4 xr[M2_BM * M2_K1 / 4 / NT];
 #pragma unroll
-  for (int i = 0; i < M2_BM * M2_K1 / 4 / 256; ++i) {
-    int g = tid + i * 256;
+  for (int i = 0; i < M2_BM * M2_K1 / 4 / NT; ++i) {
+    int g = tid + i * NT;
     int r = g / (M2_K1 / 4), k4 = g % (M2_K1 / 4);
     xr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (m0 + r < a.n) xr[i] = *reinterpret_cast<const f32x4*>(a.x1 + (long long)a.rows[m0 + r] * a.ldx1 + k4 * 4);
   }
   p2.load(a.w2, a.ldw2, tid);
 #pragma unroll
-  for (int i = 0; i < M2_BM * M2_K1 / 4 / 256; ++i) {
-    int g = tid + i * 256;
+  for (int i = 0; i < M2_BM * M2_K1 / 4 / NT; ++i) {
+    int g = tid + i * NT;
     int r = g / (M2_K1 / 4), k4 = g % (M2_K1 / 4);
     *reinterpret_cast<f32x4*>(xs + r * XS + k4 * 4) = xr[i];
   }
 
-  // ---- phase 1: hid[32 x 256]; wave w owns hidden columns [64w, 64w+64)
-  f32x4 acc1[2][4];
+  // ---- phase 1: hid[32 x 256]; wave w owns hidden columns [16 HC w, 16 HC (w + 1))
+  f32x4 acc1[2][HC];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  Phase1<KM, 0, M2_K1 / M2_BK>::run(p1, xs, wb, WSZ, tid, lane, wave, acc1);
+    for (int j = 0; j < HC; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  Phase1<KM, 0, M2_K1 / M2_BK, false, NW>::run(p1, xs, wb, WSZ, tid, lane, wave, acc1);
 
   // ---- epilogue 1: bias + ReLU, or ReLU mask from the saved forward hidden activations -> LDS (+ HBM)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < HC; ++j) {
       int m = i * 16 + (lane & 15);
-      int nn = wave * 64 + j * 16 + (lane >> 4) * 4;
+      int nn = wave * (HC * 16) + j * 16 + (lane >> 4) * 4;
       f32x4 v = acc1[i][j];
       bool live = m0 + m < a.n;
       long long row = live ? (long long)a.rows[m0 + m] : 0;
@@ -85,22 +89,22 @@ __global__ void __launch_bounds__(256, 1) mlp2_rows_kernel(Mlp2Args a) {
     }
   __syncthreads();   // hidden tile complete; phase 1's last weight tile no longer read
 
-  // ---- phase 2: out[32 x 128]; wave w owns output columns [32w, 32w+32)
-  f32x4 acc2[2][2];
+  // ---- phase 2: out[32 x 128]; wave w owns output columns [16 OC w, 16 OC (w + 1))
+  f32x4 acc2[2][OC];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  Phase2<KM, 0, M2_HD / M2_BK>::run(p2, hs, wb, WSZ, tid, lane, wave, acc2);
+    for (int j = 0; j < OC; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  Phase2<KM, 0, M2_HD / M2_BK, false, NW>::run(p2, hs, wb, WSZ, tid, lane, wave, acc2);
 
   // ---- epilogue 2: row scatter by node id
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < OC; ++j) {
       int m = i * 16 + (lane & 15);
       if (m0 + m >= a.n) continue;
-      int nn = wave * 32 + j * 16 + (lane >> 4) * 4;
+      int nn = wave * (OC * 16) + j * 16 + (lane >> 4) * 4;
       float* q = a.out + (long long)a.rows[m0 + m] * a.ldout + nn;
       f32x4 v = acc2[i][j];
       if (a.b2) {
@@ -141,9 +145,17 @@ extern "C" int mmft_mlp2_rows(const float* x1, long long ldx1, const int* rows, 
   hipStream_t st = (hipStream_t)stream;
   Mlp2Args a{x1, ldx1, rows, n, w1, ldw1, b1, w2, ldw2, b2, mask, ldmask, hid_out, ldhid, out, ldout, add_act, relu_out};
   const double fl = 2.0 * n * ((double)K1 * HD + (double)HD * D2), by = 4.0 * n * ((double)K1 + 2.0 * HD + 2.0 * D2);
-  if (weights_kmajor)
-    MMFT_LAUNCH("mlp2_rows_kernel<KM>", fl, by, mlp2_rows_kernel<true>, dim3(cdiv(n, M2_BM)), dim3(256), st, a);
-  else
-    MMFT_LAUNCH("mlp2_rows_kernel<MK>", fl, by, mlp2_rows_kernel<false>, dim3(cdiv(n, M2_BM)), dim3(256), st, a);
+  static int nw = -1;
+  if (nw < 0) {
+    const char* e = getenv("MMFT_MLP2_WAVES");         // tuning hook: 4 or 8 waves per workgroup
+    nw = (e && atoi(e) == 4) ? 4 : 8;
+  }
+  if (weights_kmajor) {
+    if (nw == 8) MMFT_LAUNCH("mlp2_rows_kernel<KM>", fl, by, (mlp2_rows_kernel<true, 8>), dim3(cdiv(n, M2_BM)), dim3(512), st, a);
+    else MMFT_LAUNCH("mlp2_rows_kernel<KM>", fl, by, (mlp2_rows_kernel<true, 4>), dim3(cdiv(n, M2_BM)), dim3(256), st, a);
+  } else {
+    if (nw == 8) MMFT_LAUNCH("mlp2_rows_kernel<MK>", fl, by, (mlp2_rows_kernel<false, 8>), dim3(cdiv(n, M2_BM)), dim3(512), st, a);
+    else MMFT_LAUNCH("mlp2_rows_kernel<MK>", fl, by, (mlp2_rows_kernel<false, 4>), dim3(cdiv(n, M2_BM)), dim3(256), st, a);
+  }
   return check_launch("mlp2_rows");
 }

@@ -32,16 +32,16 @@ struct Mlp2Args {
 // flight together (64 per thread = 256 VGPRs; the kernel runs one workgroup per CU, so the 512-entry register file
 // has room).  The K loops then only move registers -> LDS -> MFMA fragments: no global round trip sits on the
 // serial path of a level (the two-launch form paid one L2 round trip per 16-deep K step).
-template <bool KM, int N, int KT>   // tile kt of a weight with N output features; KT = number of 32-deep tiles
+template <bool KM, int N, int KT, int NT = 256>   // tile kt of a weight with N output features; KT = number of 32-deep tiles; NT threads
 struct WPanel {
-  static constexpr int PER = N * M2_BK / 4 / 256;
+  static constexpr int PER = N * M2_BK / 4 / NT;
   f32x4 r[KT][PER];
   __device__ __forceinline__ void load(const float* w, long long ldw, int tid) {
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
-        int g = tid + i * 256;
+        int g = tid + i * NT;
         if (KM) {
           int kk = g / (N / 4), n4 = g % (N / 4);
           r[kt][i] = *reinterpret_cast<const f32x4*>(w + (long long)(kt * M2_BK + kk) * ldw + n4 * 4);
@@ -55,7 +55,7 @@ struct WPanel {
   __device__ __forceinline__ void to_lds(float* dst, int tid) const {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      int g = tid + i * 256;
+      int g = tid + i * NT;
       if (KM) {
         int kk = g / (N / 4), n4 = g % (N / 4);
         *reinterpret_cast<f32x4*>(dst + kk * (N + 4) + n4 * 4) = r[KTI][i];
@@ -69,11 +69,12 @@ struct WPanel {
 
 // SINGLE = one weight tile buffer in LDS (two barriers per K step) instead of two (one barrier): the persistent
 // sweep kernel keeps its LDS footprint small so that the U-Net's kernels can share the CUs it occupies.
-template <bool KM, int KTI, int NK, bool SINGLE = false>
+template <bool KM, int KTI, int NK, bool SINGLE = false, int NW = 4>
 struct Phase1 {
+  static constexpr int HC = (M2_HD / 16) / NW;       // hidden-column subtiles per wave
   template <class P>
   static __device__ __forceinline__ void run(const P& pan, const float* xs, float* wb, int wsz, int tid, int lane, int wave,
-                                             f32x4 (&acc)[2][4]) {
+                                             f32x4 (&acc)[2][HC]) {
     constexpr int XS = M2_K1 + 8;
     constexpr int WS = KM ? (M2_HD + 4) : (M2_BK + 8);
     float* wt = wb + (SINGLE ? 0 : (KTI & 1)) * wsz;
@@ -82,28 +83,29 @@ struct Phase1 {
     __syncthreads();
 #pragma unroll
     for (int kb = 0; kb < M2_BK / 16; ++kb) {
-      float xf[2][4], wf[4][4];
+      float xf[2][4], wf[HC][4];
 #pragma unroll
       for (int i = 0; i < 2; ++i) read_frag<false, XS>(xs, i * 16, KTI * (M2_BK / 16) + kb, lane, xf[i]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) read_frag<KM, WS>(wt, wave * 64 + j * 16, kb, lane, wf[j]);
+      for (int j = 0; j < HC; ++j) read_frag<KM, WS>(wt, wave * (HC * 16) + j * 16, kb, lane, wf[j]);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < HC; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][s], xf[i][s], acc[i][j], 0, 0, 0);
     }
-    if constexpr (KTI + 1 < NK) Phase1<KM, KTI + 1, NK, SINGLE>::run(pan, xs, wb, wsz, tid, lane, wave, acc);
+    if constexpr (KTI + 1 < NK) Phase1<KM, KTI + 1, NK, SINGLE, NW>::run(pan, xs, wb, wsz, tid, lane, wave, acc);
   }
 };
 
-template <bool KM, int KTI, int NK, bool SINGLE = false>
+template <bool KM, int KTI, int NK, bool SINGLE = false, int NW = 4>
 struct Phase2 {
+  static constexpr int OC = (M2_D2 / 16) / NW;       // output-column subtiles per wave
   template <class P>
   static __device__ __forceinline__ void run(const P& pan, const float* hs, float* wb, int wsz, int tid, int lane, int wave,
-                                             f32x4 (&acc)[2][2]) {
+                                             f32x4 (&acc)[2][OC]) {
     constexpr int HS = M2_HD + 8;
     constexpr int WS = KM ? (M2_D2 + 4) : (M2_BK + 8);
     float* wt = wb + (SINGLE ? 0 : (KTI & 1)) * wsz;
@@ -112,20 +114,20 @@ struct Phase2 {
     __syncthreads();
 #pragma unroll
     for (int kb = 0; kb < M2_BK / 16; ++kb) {
-      float xf[2][4], wf[2][4];
+      float xf[2][4], wf[OC][4];
 #pragma unroll
       for (int i = 0; i < 2; ++i) read_frag<false, HS>(hs, i * 16, KTI * (M2_BK / 16) + kb, lane, xf[i]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) read_frag<KM, WS>(wt, wave * 32 + j * 16, kb, lane, wf[j]);
+      for (int j = 0; j < OC; ++j) read_frag<KM, WS>(wt, wave * (OC * 16) + j * 16, kb, lane, wf[j]);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < OC; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][s], xf[i][s], acc[i][j], 0, 0, 0);
     }
-    if constexpr (KTI + 1 < NK) Phase2<KM, KTI + 1, NK, SINGLE>::run(pan, hs, wb, wsz, tid, lane, wave, acc);
+    if constexpr (KTI + 1 < NK) Phase2<KM, KTI + 1, NK, SINGLE, NW>::run(pan, hs, wb, wsz, tid, lane, wave, acc);
   }
 };
 
