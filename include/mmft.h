@@ -192,8 +192,9 @@ int mmft_bn_train_fwd(const float* x, float* y, const float* gamma, const float*
                       float* save_mean, float* save_invstd, int relu, float* workspace,
                       long long workspace_bytes, int device, void* stream);
 /* g = gy * (y > 0 if relu); dgamma = sum g*xhat; dbeta = sum g;
- * dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) with means per group */
-int mmft_bn_train_bwd(const float* gy, const float* x, const float* y, const float* gamma,
+ * dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) with means per group.  With `beta` given the ReLU mask is
+ * recomputed from x by the forward's own affine (same rounding sequence) and y may be NULL: 5 tensor passes, not 7 */
+int mmft_bn_train_bwd(const float* gy, const float* x, const float* y, const float* gamma, const float* beta,
                       const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                       float* dbeta, int groups, long long rows, int C, int relu, float* workspace,
                       long long workspace_bytes, int device, void* stream);

@@ -155,6 +155,12 @@ __device__ __forceinline__ void bn_running_update(const float* __restrict__ save
   running_var[c] = (float)rv;
 }
 
+// y = (x - mean) * invstd * gamma + beta with a fixed rounding sequence: the backward kernels recompute the ReLU mask
+// from x with the SAME function instead of reading y back (two of the seven tensor passes of the BatchNorm backward)
+__device__ __forceinline__ float bn_affine(float x, float mean, float invstd, float gamma, float beta) {
+  return __fmaf_rn(__fmul_rn(__fsub_rn(x, mean), invstd), gamma, beta);
+}
+
 template <int VEC>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -171,12 +177,12 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
       f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float t = (v[j] - mean[g * C + c + j]) * invstd[g * C + c + j] * gamma[c + j] + beta[c + j];
+        float t = bn_affine(v[j], mean[g * C + c + j], invstd[g * C + c + j], gamma[c + j], beta[c + j]);
         v[j] = (relu && !(t > 0.f)) ? 0.f : t;
       }
       *reinterpret_cast<f32x4*>(y + i) = v;
     } else {
-      float t = (x[i] - mean[g * C + c]) * invstd[g * C + c] * gamma[c] + beta[c];
+      float t = bn_affine(x[i], mean[g * C + c], invstd[g * C + c], gamma[c], beta[c]);
       y[i] = (relu && !(t > 0.f)) ? 0.f : t;
     }
   }
@@ -188,7 +194,8 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ y, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, long long rows, int C,
                                                              int blocks_per_group, int relu,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta) {
   __shared__ float red[2][256 * VEC];
   int grp = blockIdx.x / blocks_per_group, blk = blockIdx.x % blocks_per_group;
   long long base = (long long)grp * rows * C;
@@ -202,18 +209,24 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __rest
 #pragma unroll
   for (int j = 0; j < VEC; ++j) s[j] = sx[j] = 0.f;
   if (rl < rstep) {
-    float mu[VEC], is[VEC];
+    float mu[VEC], is[VEC], ga[VEC], be[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       mu[j] = mean[grp * C + c + j];
       is[j] = invstd[grp * C + c + j];
+      ga[j] = beta ? gamma[c + j] : 0.f;
+      be[j] = beta ? beta[c + j] : 0.f;
     }
     for (long long r = r0 + rl; r < r1; r += rstep) {
       long long i = base + r * C + c;
       if (VEC == 4) {
         f32x4 g = *reinterpret_cast<const f32x4*>(gy + i);
         f32x4 xv = *reinterpret_cast<const f32x4*>(x + i);
-        if (relu) {
+        if (relu && beta) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (!(bn_affine(xv[j], mu[j], is[j], ga[j], be[j]) > 0.f)) g[j] = 0.f;
+        } else if (relu) {
           f32x4 yv = *reinterpret_cast<const f32x4*>(y + i);
 #pragma unroll
           for (int j = 0; j < 4; ++j)
@@ -226,7 +239,7 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __rest
         }
       } else {
         float g = gy[i];
-        if (relu && !(y[i] > 0.f)) g = 0.f;
+        if (relu && !((beta ? bn_affine(x[i], mu[0], is[0], ga[0], be[0]) : y[i]) > 0.f)) g = 0.f;
         s[0] += g;
         sx[0] += g * (x[i] - mu[0]) * is[0];
       }
@@ -287,7 +300,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, float* __restrict__ dx,
                                                            long long rows, int C, long long total, int relu, int groups,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           const float* __restrict__ beta) {
   if (blockIdx.x == 0) bn_bwd_params(coef, groups, rows, C, dgamma, dbeta);
   long long per_group = rows * C;
   for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VEC; i < total;
@@ -297,7 +311,11 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
     if (VEC == 4) {
       f32x4 gg = *reinterpret_cast<const f32x4*>(gy + i);
       f32x4 xv = *reinterpret_cast<const f32x4*>(x + i);
-      if (relu) {
+      if (relu && beta) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (!(bn_affine(xv[j], mean[g * C + c + j], invstd[g * C + c + j], gamma[c + j], beta[c + j]) > 0.f)) gg[j] = 0.f;
+      } else if (relu) {
         f32x4 yv = *reinterpret_cast<const f32x4*>(y + i);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -313,7 +331,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
       *reinterpret_cast<f32x4*>(dx + i) = o;
     } else {
       float gg = gy[i];
-      if (relu && !(y[i] > 0.f)) gg = 0.f;
+      if (relu && !((beta ? bn_affine(x[i], mean[g * C + c], invstd[g * C + c], gamma[c], beta[c]) : y[i]) > 0.f)) gg = 0.f;
       float is = invstd[g * C + c];
       float xh = (x[i] - mean[g * C + c]) * is;
       dx[i] = gamma[c] * is * (gg - coef[(g * 2) * C + c] - xh * coef[(g * 2 + 1) * C + c]);
@@ -552,33 +570,34 @@ int mmft_bn_train_fwd(const float* x, float* y, const float* gamma, const float*
   return check_launch("bn_train_fwd");
 }
 
-int mmft_bn_train_bwd(const float* gy, const float* x, const float* y, const float* gamma, const float* save_mean,
-                      const float* save_invstd, float* dx, float* dgamma, float* dbeta, int groups, long long rows, int C,
-                      int relu, float* workspace, long long workspace_bytes, int device, void* stream) {
+int mmft_bn_train_bwd(const float* gy, const float* x, const float* y, const float* gamma, const float* beta,
+                      const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta, int groups,
+                      long long rows, int C, int relu, float* workspace, long long workspace_bytes, int device,
+                      void* stream) {
   MMFT_REQUIRE(gy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "bn_train_bwd: null pointer");
-  MMFT_REQUIRE(!relu || y, "bn_train_bwd: relu backward needs the forward output");
+  MMFT_REQUIRE(!relu || y || beta, "bn_train_bwd: relu backward needs beta (mask recomputed from x) or the forward output");
   MMFT_REQUIRE(groups > 0 && rows > 0 && C > 0 && C <= 256, "bn_train_bwd: bad sizes (C <= 256 supported)");
   MMFT_REQUIRE(workspace && workspace_bytes >= mmft_bn_workspace_bytes(groups, rows, C), "bn_train_bwd: workspace too small");
   DeviceGuard dg(device);
   hipStream_t st = (hipStream_t)stream;
   int bpg = bn_blocks(rows);
   float* coef = workspace + (long long)groups * bpg * 2 * C;
-  ProfScope ps("bn_train_bwd(3 kernels)", 0.0, 7.0 * 4.0 * groups * rows * C, st);
+  ProfScope ps("bn_train_bwd(3 kernels)", 0.0, (beta ? 5.0 : 7.0) * 4.0 * groups * rows * C, st);
   const bool v4 = (C % 4 == 0) && aligned16(x) && aligned16(gy) && aligned16(dx) && (!y || aligned16(y));
   if (v4)
     hipLaunchKernelGGL(bn_bwd_partial_kernel<4>, dim3(groups * bpg), dim3(256), 0, st, gy, x, y, save_mean, save_invstd, rows,
-                       C, bpg, relu, workspace);
+                       C, bpg, relu, workspace, gamma, beta);
   else
     hipLaunchKernelGGL(bn_bwd_partial_kernel<1>, dim3(groups * bpg), dim3(256), 0, st, gy, x, y, save_mean, save_invstd, rows,
-                       C, bpg, relu, workspace);
+                       C, bpg, relu, workspace, gamma, beta);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(groups * C), dim3(64), 0, st, workspace, rows, C, bpg, coef);
   long long total = (long long)groups * rows * C;
   if (v4)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_grid(total / 4)), dim3(256), 0, st, gy, x, y, gamma, save_mean,
-                       save_invstd, coef, dx, rows, C, total, relu, groups, dgamma, dbeta);
+                       save_invstd, coef, dx, rows, C, total, relu, groups, dgamma, dbeta, beta);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_grid(total)), dim3(256), 0, st, gy, x, y, gamma, save_mean,
-                       save_invstd, coef, dx, rows, C, total, relu, groups, dgamma, dbeta);
+                       save_invstd, coef, dx, rows, C, total, relu, groups, dgamma, dbeta, beta);
   return check_launch("bn_train_bwd");
 }
 

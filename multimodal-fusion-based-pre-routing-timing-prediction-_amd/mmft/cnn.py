@@ -56,17 +56,18 @@ class BnReluFn(torch.autograd.Function):
                                            relu, per_sample)
         ctx.relu = relu
         ctx.sinks = (gradsink.of(gamma), gradsink.of(beta))
-        ctx.save_for_backward(xn, y, gamma, mean, invstd)
+        # the backward recomputes the ReLU mask from x with the forward's own affine: y is not kept for it
+        ctx.save_for_backward(xn, gamma, beta, mean, invstd)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        xn, y, gamma, mean, invstd = ctx.saved_tensors
+        xn, gamma, beta, mean, invstd = ctx.saved_tensors
         sg, sb = ctx.sinks
         both = sg is not None and sb is not None and gradsink.fresh(sg) and gradsink.fresh(sb)
         outs = (gradsink.take(sg), gradsink.take(sb)) if both else (None, None)
-        dx, dgamma, dbeta = ops.bn_train_bwd(ops.to_nhwc(gy), xn, y, gamma.detach(), mean, invstd, ctx.relu,
-                                             dgamma=outs[0], dbeta=outs[1])
+        dx, dgamma, dbeta = ops.bn_train_bwd(ops.to_nhwc(gy), xn, None, gamma.detach(), mean, invstd, ctx.relu,
+                                             dgamma=outs[0], dbeta=outs[1], beta=beta.detach())
         if both:
             dgamma = dbeta = None
         return dx, dgamma, dbeta, None, None, None, None, None, None

@@ -485,7 +485,7 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu,
     return y, mean, invstd
 
 
-def bn_train_bwd(gy, x, y, gamma, mean, invstd, relu, dgamma=None, dbeta=None):
+def bn_train_bwd(gy, x, y, gamma, mean, invstd, relu, dgamma=None, dbeta=None, beta=None):
     _nhwc(gy, 'gy'); _nhwc(x, 'x')
     N, C, H, W = x.shape
     groups = mean.shape[0]
@@ -499,7 +499,7 @@ def bn_train_bwd(gy, x, y, gamma, mean, invstd, relu, dgamma=None, dbeta=None):
             raise ValueError(f'bn_train_bwd: {nm} shape')
     ws = lib.workspace(x.device, lib.query('mmft_bn_workspace_bytes', groups, rows, C))
     dev, st = lib.stream_args(x)
-    lib.call('mmft_bn_train_bwd', gy, x, y, gamma, mean, invstd, dx, dgamma, dbeta, groups, rows, C, int(relu), ws,
+    lib.call('mmft_bn_train_bwd', gy, x, y, gamma, beta, mean, invstd, dx, dgamma, dbeta, groups, rows, C, int(relu), ws,
              ws.numel() * 4, dev, st)
     return dx, dgamma, dbeta
 
