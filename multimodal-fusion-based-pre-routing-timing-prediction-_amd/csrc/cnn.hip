@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const float* __restrict
     float shift[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) shift[j] = xg[c + j];
+#pragma unroll 4
     for (long long r = r0 + rl; r < r1; r += rstep) {
       if (VEC == 4) {
         f32x4 v = *reinterpret_cast<const f32x4*>(xg + r * C + c);
@@ -217,6 +218,7 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __rest
       ga[j] = beta ? gamma[c + j] : 0.f;
       be[j] = beta ? beta[c + j] : 0.f;
     }
+#pragma unroll 4
     for (long long r = r0 + rl; r < r1; r += rstep) {
       long long i = base + r * C + c;
       if (VEC == 4) {
