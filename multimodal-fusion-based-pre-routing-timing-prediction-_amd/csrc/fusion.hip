@@ -148,13 +148,14 @@ __global__ void __launch_bounds__(256) masked_fc_fwd_runs_kernel(const int* __re
 // cells [j S/J, (j+1) S/J) and walks their boundary lists with four index -> batch-row -> gradient-row chains in flight;
 // D stays in LDS.  Stage 2 (lane 0's channel groups): suffix sums of D give dg[c] = d loss / d(f[c] wT[c]); emit the
 // design's dwT slab (f dg) and df[c] = <dg, wT[c]> (wave-shuffle reduction over the GROUPS lanes).  Fixed orders.
+constexpr int MFB_THREADS = 512;      // 16 entry lanes x 32 channel groups at Dout = 128: 4 cells per lane (256: 246 us, 512: 192 us, 1024: 231 us)
 template <int GROUPS>
-__global__ void __launch_bounds__(256) masked_fc_bwd_runs_kernel(const int* __restrict__ bptr, const int* __restrict__ bcode,
+__global__ void __launch_bounds__(MFB_THREADS) masked_fc_bwd_runs_kernel(const int* __restrict__ bptr, const int* __restrict__ bcode,
                                                                  const int* __restrict__ first, const int* __restrict__ next,
                                                                  const float* __restrict__ gout, const float* __restrict__ f,
                                                                  const float* __restrict__ wT, float* __restrict__ dwT,
                                                                  float* __restrict__ df, int P, int S) {
-  constexpr int Dout = GROUPS * 4, J = 256 / GROUPS;
+  constexpr int Dout = GROUPS * 4, J = MFB_THREADS / GROUPS;
   extern __shared__ __attribute__((aligned(16))) float dl[];            // [S][Dout]
   const int b = blockIdx.y, blk = blockIdx.x;
   const int j = threadIdx.x / GROUPS, c4 = threadIdx.x % GROUPS;
@@ -424,9 +425,9 @@ int mmft_masked_fc_bwd_runs(const int* bnd_ptr, const int* bnd_code, const int* 
   MMFT_REQUIRE(bnd_ptr && bnd_code && first && next && gout && f && wT && dwT && df, "masked_fc_bwd_runs: null pointer");
   const int groups = Dout / 4;
   MMFT_REQUIRE(B > 0 && P > 0 && S > 0 && P % S == 0 && Dout % 4 == 0 && groups >= 1 && groups <= 64 &&
-                   (groups & (groups - 1)) == 0 && S % (256 / groups) == 0 && (long long)S * Dout * 4 <= 65536,
+                   (groups & (groups - 1)) == 0 && S % (MFB_THREADS / groups) == 0 && (long long)S * Dout * 4 <= 65536,
                "masked_fc_bwd_runs: Dout / 4 must be a power of two <= 64, the block of S cells x Dout must fit 64 KB of "
-               "LDS and S be a multiple of 256 / (Dout / 4)");
+               "LDS and S be a multiple of MFB_THREADS / (Dout / 4)");
   MMFT_REQUIRE(aligned16(gout) && aligned16(wT) && aligned16(dwT), "masked_fc_bwd_runs: 16-byte alignment");
   MMFT_REQUIRE(B == 1 || (workspace && workspace_bytes >= mmft_masked_fc_bwd_runs_workspace_bytes(B, P, Dout) &&
                           aligned16(workspace)),
@@ -437,7 +438,7 @@ int mmft_masked_fc_bwd_runs(const int* bnd_ptr, const int* bnd_code, const int* 
   const dim3 grid(P / S, B);
   const size_t lds = (size_t)S * Dout * 4;
 #define MMFT_RUNS(G)                                                                                                   \
-  MMFT_LAUNCH_LDS("masked_fc_bwd_runs_kernel", 0.0, 0.0, masked_fc_bwd_runs_kernel<G>, grid, dim3(256), lds, st, bnd_ptr, \
+  MMFT_LAUNCH_LDS("masked_fc_bwd_runs_kernel", 0.0, 0.0, masked_fc_bwd_runs_kernel<G>, grid, dim3(MFB_THREADS), lds, st, bnd_ptr, \
                   bnd_code, first, next, gout, f, wT, slabs, df, P, S)
   switch (groups) {
     case 1: MMFT_RUNS(1); break;

@@ -186,7 +186,7 @@ class MaskedFcFn(torch.autograd.Function):
         df = torch.empty(B * P, dtype=torch.float32, device=f.device)
         groups = Dout // 4
         if USE_RUNS and pm.masks.run_block and groups <= 64 and groups & (groups - 1) == 0 and \
-                pm.masks.run_block * Dout * 4 <= 65536 and pm.masks.run_block % (256 // groups) == 0:
+                pm.masks.run_block * Dout * 4 <= 65536 and pm.masks.run_block % (512 // groups) == 0:
             ws = lib.workspace(f.device, lib.query('mmft_masked_fc_bwd_runs_workspace_bytes', B, P, Dout))
             lib.call('mmft_masked_fc_bwd_runs', pm.masks.bnd_ptr, pm.masks.bnd_code, pm.first, pm.next, g, f, wT, dwT, df,
                      B, P, Dout, pm.masks.run_block, ws, ws.numel() * 4, dev, st)
