@@ -15,7 +15,14 @@ Rank 0 prints ONE JSON line (contract in the task statement) with two extra obje
                 HIP events recorded by the library on the launch stream (mmft_prof_*), in a separate
                 instrumented region of the same steps so that `value` is not perturbed by the events;
   cpu_baseline  the CPU oracle (oracle/restatement.py, kind "port") timed on this host on a bounded
-                sample (one design per step as the reference does, 1 warm-up + 2 timed steps).
+                sample (one design per step as the reference does; 2 warm-up + 10 timed steps, median, anomaly
+                detection off, plus 3 timed steps with torch.autograd.set_detect_anomaly(True) as the reference
+                leaves it on at src/train.py:452).
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts N ranks itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`) BEFORE it touches the
+GPU and exits with their status; rank 0 prints the JSON line.  Launched under torchrun already (the driver's form), it
+is one of the ranks.
 """
 import argparse
 import ctypes
@@ -52,20 +59,41 @@ def _norm_kernel(name):
     return name
 
 
+def csrc_fingerprint():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, include/mmft.h): what a PMC table must have been taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(PKG, 'csrc')
+    files = sorted(f for f in os.listdir(src) if f.endswith(('.hip', '.h'))) if os.path.isdir(src) else []
+    for f in files:
+        with open(os.path.join(src, f), 'rb') as fh:
+            h.update(f.encode() + b'\0' + fh.read())
+    with open(os.path.join(ROOT, 'include', 'mmft.h'), 'rb') as fh:
+        h.update(fh.read())
+    return h.hexdigest()
+
+
+PMC_TABLE = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm_traffic.json')
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_hbm_traffic.json:
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this bench, KiB units, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  None when the kernel has no entry."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r02_pmc_hbm_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this bench, KiB units, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  The table is stamped with the fingerprint of the kernel sources it was
+    measured on: (None, reason) when the stamp does not match the sources in this tree or the kernel has no entry -
+    a stale table is never reported."""
+    if not os.path.exists(PMC_TABLE):
+        return None, 'no PMC table committed'
+    with open(PMC_TABLE) as f:
         table = json.load(f)
+    stamp = table.get('__stamp__', {})
+    if stamp.get('csrc_sha256') != csrc_fingerprint():
+        return None, 'PMC table was taken on other kernel sources (stamp mismatch)'
     want = _norm_kernel(kernel)
     for k, v in table.items():
-        if _norm_kernel(k) == want:
-            return v['hbm_bytes_per_launch']
-    return None
+        if k != '__stamp__' and _norm_kernel(k) == want:
+            return v['hbm_bytes_per_launch'], 'rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, ' + os.path.basename(PMC_TABLE)
+    return None, 'kernel not in the PMC table'
 
 
 def prof_report():
@@ -81,8 +109,9 @@ def prof_report():
     return rows
 
 
-def cpu_baseline(design, pm_state, pc_state, batch_paths, steps=2):
-    """The CPU oracle's train step (reference-shaped: one design per step), timed on this host's cores."""
+def cpu_baseline(design, pm_state, pc_state, batch_paths, steps=10, warm=2, anomaly_steps=3):
+    """The CPU oracle's train step (reference-shaped: one design per step), timed on this host's cores: `warm` untimed
+    + `steps` timed steps with anomaly detection off (median), then `anomaly_steps` timed steps with it on."""
     from oracle import restatement as R
     # the GPU box gives one GPU's share of the host: 16 cores (more threads than that only oversubscribe)
     ncores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
@@ -91,17 +120,45 @@ def cpu_baseline(design, pm_state, pc_state, batch_paths, steps=2):
     orc = R.OracleTrainer(pm_state, pc_state)
     csr = R.design_csr(design)
     rng = np.random.default_rng(7)
-    t = []
-    for i in range(steps + 1):
-        ids = rng.permutation(design.num_paths)[:min(batch_paths, design.num_paths)].tolist()
-        t0 = time.perf_counter()
-        orc.step(design, csr, ids)
-        t.append(time.perf_counter() - t0)
-        log(f'cpu oracle step {i}: {t[-1]:.2f} s')
-    sec = float(np.mean(t[1:]))
+
+    def run(n, tag):
+        t = []
+        for i in range(n):
+            ids = rng.permutation(design.num_paths)[:min(batch_paths, design.num_paths)].tolist()
+            t0 = time.perf_counter()
+            orc.step(design, csr, ids)
+            t.append(time.perf_counter() - t0)
+            log(f'cpu oracle {tag} step {i}: {t[-1]:.2f} s')
+        return t
+    run(warm, 'warm-up')
+    sec = float(np.median(run(steps, 'timed')))
+    sec_an = None
+    if anomaly_steps:
+        with torch.autograd.set_detect_anomaly(True):
+            sec_an = float(np.median(run(anomaly_steps, 'anomaly-on')))
     return dict(value=1.0 / sec, unit='designs/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'{steps} timed steps (+1 warm-up) of ONE config-B design per step, fp32 torch CPU, '
-                       f'anomaly detection off; {sec:.2f} s/step')
+                sample=f'median of {steps} timed steps (+{warm} warm-up) of ONE config-B design per step (the '
+                       f'reference steps one design at a time), fp32 torch CPU, anomaly detection off; {sec:.2f} s/step',
+                value_anomaly_on=(1.0 / sec_an) if sec_an else None,
+                sample_anomaly_on=(f'median of {anomaly_steps} timed steps with torch.autograd.set_detect_anomaly(True) '
+                                   f'(src/train.py:452); {sec_an:.2f} s/step') if sec_an else None)
+
+
+def self_launch(args):
+    """--gpus N > 1 without a torchrun environment: start the N ranks ourselves.  Nothing in this process has touched
+    the GPU yet (importing torch does not), and it only waits for the child: no exec of a GPU process."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log('starting %d ranks: %s' % (args.gpus, ' '.join(cmd)))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -121,9 +178,17 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying one HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help='f32: exact fp32 MFMA everywhere (the 1e-4 parity mode); bf16: bf16 operands / fp32 accumulate '
+                         'on the MFMA-bound contractions (BASELINE config B names bf16)')
+    ap.add_argument('--cpu-steps', type=int, default=10)
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        log(f'WORLD_SIZE={world} differs from --gpus {args.gpus}: running (and reporting) {world} ranks')
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if os.environ.get('MMFT_DIST_BACKEND', 'nccl') != 'nccl':
@@ -189,7 +254,8 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    mae = float((hats - ts.batch.arrival[torch.as_tensor(tl, device=dev).long()].squeeze(-1)).abs().mean())
+    # endpoint ids in the index space of batch.arrival (renumbered, device side) - NOT the original ids step() returns
+    mae = float((hats - ts.batch.arrival[ts.last_ends.long()].squeeze(-1)).abs().mean())
 
     roofline = None
     if not args.no_roofline:
@@ -223,7 +289,7 @@ def main():
             ach = top['bytes'] / (top['ms'] * 1e-3) / 1e9
             roofline = dict(bound='hbm', achieved=ach, peak=PEAK_HBM_GBS, unit='GB/s', frac=ach / PEAK_HBM_GBS,
                             traffic=None)
-        roofline['traffic'] = pmc_traffic(top['name'])
+        roofline['traffic'], roofline['traffic_source'] = pmc_traffic(top['name'])
         roofline.update(kernel=top['name'], launches_per_step=top['launches'] / nprof,
                         avg_launch_us=per_launch_ms * 1e3, share_of_device_time=top['ms'] / total_ms,
                         device_ms_per_step=total_ms / nprof,
@@ -243,7 +309,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log('timing the CPU oracle (bounded sample)')
-        cpu = cpu_baseline(designs[0], pm_state, pc_state, args.batch_paths)
+        cpu = cpu_baseline(designs[0], pm_state, pc_state, args.batch_paths, steps=args.cpu_steps)
 
     if rank == 0:
         total_designs = args.designs * world * args.steps

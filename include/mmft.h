@@ -162,6 +162,11 @@ int mmft_gather_rows(const float* src, long long lds, const int* idx, int n, int
                      int device, void* stream);
 int mmft_scatter_add_rows(float* dst, long long ldd, const int* idx, int n, int D, const float* src,
                           long long lds, int device, void* stream);
+/* the same sum without atomics: `order` is a STABLE argsort of idx (order[p] = batch row at sorted position p); each
+ * destination adds its rows in batch order, so endpoints duplicated by oversampling (src/train.py:377-380) give
+ * bitwise reproducible gradients */
+int mmft_scatter_add_rows_sorted(float* dst, long long ldd, const int* idx, const int* order, int n, int D,
+                                 const float* src, long long lds, int device, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Layout-image CNN  --  replaces nn.Conv2d / BatchNorm2d(train) / ReLU / MaxPool2d / AvgPool2d /
@@ -287,6 +292,13 @@ int mmft_adam_step(float* p, const float* g, float* m, float* v, long long n, fl
 int mmft_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* step_scalars,
                        float beta1, float beta2, float eps, float weight_decay, float gscale,
                        int device, void* stream);
+
+/* same, with the optimizer's step counter kept in DEVICE memory: state[0] = steps taken so far (advanced by the
+ * launch), state[1] = 0 (scratch ticket).  Both bias corrections are derived in the kernel from state[0] + 1, so the
+ * host uploads nothing per step and the launch can be captured in a HIP graph and replayed any number of times, with
+ * the host running ahead of the device.  state is two int32 words, zeroed by the caller before the first step. */
+int mmft_adam_step_counted(float* p, const float* g, float* m, float* v, long long n, int* state, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, float gscale, int device, void* stream);
 
 /* ---- design preprocessing: the graph-side steps the reference runs on networkx in Python ---- */
 /* Longest-path levels from the primary inputs `pis` (src/verilog_parser_asap7.py:1452-1517, cal_topo_level: frontier

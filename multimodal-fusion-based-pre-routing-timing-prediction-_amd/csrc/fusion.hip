@@ -340,6 +340,41 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// Adam with the step counter in DEVICE memory: state[0] = optimizer steps taken so far, state[1] = arrival ticket.
+// Every workgroup reads the counter when it starts, derives both bias corrections itself (fp64, as torch does on the
+// host) and the last workgroup to finish advances the counter - nothing step-dependent is uploaded by the host, so
+// a HIP-graph replay (or a host running several steps ahead of the device) cannot pair a step with another step's
+// scalars.
+__global__ void __launch_bounds__(256) adam_counted_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v, long long n,
+                                                           int* __restrict__ state, float lr, float beta1, float beta2,
+                                                           float eps, float wd, float gscale) {
+  const int t = state[0] + 1;
+  const double bc1 = 1.0 - pow((double)beta1, (double)t);
+  const double bc2 = 1.0 - pow((double)beta2, (double)t);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale, pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    float mi = m[i], vi = v[i];
+    mi = mi + (gi - mi) * (1.0f - beta1);
+    vi = vi * beta2 + (1.0f - beta2) * gi * gi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+  }
+  __syncthreads();                                   // every thread of this workgroup has read state[0]
+  if (threadIdx.x == 0) {
+    int ticket = atomicAdd(state + 1, 1);
+    if (ticket == (int)gridDim.x - 1) {              // last workgroup to finish: all others started (and read) before
+      state[1] = 0;
+      state[0] = t;
+    }
+  }
+}
+
 }  // namespace mmft
 
 using namespace mmft;
@@ -479,6 +514,16 @@ int mmft_adam_step(float* p, const float* g, float* m, float* v, long long n, fl
   DeviceGuard dg(device);
   MMFT_LAUNCH("adam_kernel", 0.0, 28.0 * n, adam_kernel, dim3(ew_grid(n)), dim3(256), (hipStream_t)stream, p, g, m, v, n, lr / bias_correction1, beta1, beta2, eps, weight_decay, sqrtf(bias_correction2), gscale, (const float*)nullptr);
   return check_launch("adam_step");
+}
+
+int mmft_adam_step_counted(float* p, const float* g, float* m, float* v, long long n, int* state, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, float gscale, int device, void* stream) {
+  MMFT_REQUIRE(p && g && m && v && state && n >= 0, "adam_step_counted: bad args");
+  MMFT_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "adam_step_counted: betas must be in [0, 1)");
+  if (n == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  MMFT_LAUNCH("adam_kernel", 0.0, 28.0 * n, adam_counted_kernel, dim3(ew_grid(n)), dim3(256), (hipStream_t)stream, p, g, m, v, n, state, lr, beta1, beta2, eps, weight_decay, gscale);
+  return check_launch("adam_step_counted");
 }
 
 int mmft_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* step_scalars, float beta1,

@@ -174,6 +174,28 @@ __global__ void __launch_bounds__(256) scatter_add_rows_kernel(float* __restrict
   }
 }
 
+// dst[idx[t]] += src[t] for t in the order `order` (a stable sort of idx): the first position of every run of equal
+// destinations adds the run's rows one after another in batch order - no atomics, so duplicated endpoints
+// (oversampling, src/train.py:377-380) give bitwise reproducible sums.
+__global__ void __launch_bounds__(256) scatter_add_rows_sorted_kernel(float* __restrict__ dst, long long ldd,
+                                                                      const int* __restrict__ idx,
+                                                                      const int* __restrict__ order, int n, int D,
+                                                                      const float* __restrict__ src, long long lds) {
+  MMFT_NODE_LOOP(n, D) {
+    int p = (int)(t / groups), c = (int)(t - (long long)p * groups) * 4;
+    const int v = idx[order[p]];
+    if (p > 0 && idx[order[p - 1]] == v) continue;            // not the first of its run
+    float* q = dst + (long long)v * ldd + c;
+    f32x4 acc = ld4(q);
+    for (int r = p; r < n; ++r) {
+      const int tr = order[r];
+      if (idx[tr] != v) break;
+      acc += ld4(src + (long long)tr * lds + c);
+    }
+    st4(q, acc);
+  }
+}
+
 static inline int node_grid(int n, int D) { return ew_grid((long long)n * (D / 4)); }
 
 }  // namespace mmft
@@ -298,6 +320,19 @@ int mmft_scatter_add_rows(float* dst, long long ldd, const int* idx, int n, int 
   DeviceGuard dg(device);
   MMFT_LAUNCH("scatter_add_rows_kernel", 0.0, 2.0 * 4.0 * n * D, scatter_add_rows_kernel, dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, dst, ldd, idx, n, D, src, lds);
   return check_launch("scatter_add_rows");
+}
+
+int mmft_scatter_add_rows_sorted(float* dst, long long ldd, const int* idx, const int* order, int n, int D,
+                                 const float* src, long long lds, int device, void* stream) {
+  CHECK_ROWS("scatter_add_rows_sorted");
+  MMFT_REQUIRE(src && dst && ((idx && order) || n == 0), "scatter_add_rows_sorted: null pointer");
+  MMFT_REQUIRE(lds >= D && ldd >= D && lds % 4 == 0 && ldd % 4 == 0 && aligned16(src) && aligned16(dst),
+               "scatter_add_rows_sorted: rows must be 16-byte aligned");
+  if (n == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  MMFT_LAUNCH("scatter_add_rows_sorted_kernel", 0.0, 3.0 * 4.0 * n * D, scatter_add_rows_sorted_kernel,
+              dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, dst, ldd, idx, order, n, D, src, lds);
+  return check_launch("scatter_add_rows_sorted");
 }
 
 }  // extern "C"

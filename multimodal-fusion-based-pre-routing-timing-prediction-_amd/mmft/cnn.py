@@ -69,6 +69,8 @@ class BnReluFn(torch.autograd.Function):
         dx, dgamma, dbeta = ops.bn_train_bwd(ops.to_nhwc(gy), xn, None, gamma.detach(), mean, invstd, ctx.relu,
                                              dgamma=outs[0], dbeta=outs[1], beta=beta.detach())
         if both:
+            gradsink.taken(sg)
+            gradsink.taken(sb)
             dgamma = dbeta = None
         return dx, dgamma, dbeta, None, None, None, None, None, None
 

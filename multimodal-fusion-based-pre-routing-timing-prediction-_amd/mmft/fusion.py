@@ -252,26 +252,40 @@ class FlatAdam:
     torch's Adam skips them.
     """
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        self.params = [p for p in params]
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, buckets=None):
+        """buckets: optional [(name, [params...]), ...] partition of `params`; the flat buffers are laid out bucket
+        after bucket, so each bucket is one contiguous range (one all-reduce + one Adam launch of its own, issued as
+        soon as its gradients exist: mmft.dist.GradReducer).  Default: one bucket holding everything."""
+        params = [p for p in params]
+        if buckets is None:
+            buckets = [('all', params)]
+        self.params = [p for _, ps in buckets for p in ps]
         if not self.params:
             raise ValueError('FlatAdam: no parameters')
+        if len(self.params) != len(params) or {id(p) for p in self.params} != {id(p) for p in params}:
+            raise ValueError('FlatAdam: the buckets must partition the parameter list')
         dev = self.params[0].device
         if dev.type != 'cuda':
             raise RuntimeError('FlatAdam runs on the GPU only')
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
-        sizes = [p.numel() for p in self.params]
         # 16-byte aligned slots so that every view stays vector-load friendly
         self.offsets, off = [], 0
-        for n in sizes:
-            self.offsets.append(off)
-            off += (n + 3) // 4 * 4
+        self.bucket_ranges, self.bucket_params = [], []
+        for name, ps in buckets:
+            lo = off
+            for p in ps:
+                self.offsets.append(off)
+                off += (p.numel() + 3) // 4 * 4
+            self.bucket_ranges.append((name, lo, off))
+            self.bucket_params.append(list(ps))
         self.n = off
         self.flat_param = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
         self.m = torch.zeros(off, dtype=torch.float32, device=dev)
         self.v = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.step_count = 0
+        self.step_count = 0                # host mirror of state[:, 0]
+        # per bucket: [optimizer steps taken, arrival ticket] - the step counter lives on the device
+        self.state = torch.zeros((len(buckets), 2), dtype=torch.int32, device=dev)
         for p, o in zip(self.params, self.offsets):
             n = p.numel()
             # keep the parameter's logical shape AND its memory order (channels_last conv weights etc.)
@@ -289,37 +303,36 @@ class FlatAdam:
         self.flat_grad.zero_()
         gradsink.new_step()
 
-    def step(self, gscale=1.0):
-        self.step_count += 1
+    def step_bucket(self, i, gscale=1.0):
+        """Adam over bucket i only (its own device-side step counter); the caller keeps `step_count` in step."""
+        _, lo, hi = self.bucket_ranges[i]
+        if hi == lo:
+            return
         b1, b2 = self.betas
-        bc1 = 1.0 - b1 ** self.step_count
-        bc2 = 1.0 - b2 ** self.step_count
         dev, st = lib.stream_args(self.flat_param)
-        lib.call('mmft_adam_step', self.flat_param, self.flat_grad, self.m, self.v, self.n, float(self.lr), float(b1),
-                 float(b2), float(self.eps), float(self.wd), float(bc1), float(bc2), float(gscale), dev, st)
+        lib.call('mmft_adam_step_counted', self.flat_param[lo:hi], self.flat_grad[lo:hi], self.m[lo:hi], self.v[lo:hi],
+                 hi - lo, self.state[i], float(self.lr), float(b1), float(b2), float(self.eps), float(self.wd),
+                 float(gscale), dev, st)
 
-    # ---- graph-capturable form: the step-dependent scalars live in device memory
-    def prepare_step(self):
-        """Advance the step counter and upload lr/bc1, sqrt(bc2) (call OUTSIDE graph capture/replay)."""
-        import math
-        self.ensure_scalars()
+    def step(self, gscale=1.0):
+        """One Adam step.  The step counter lives in device memory (`self.state[:, 0]`) and the kernel derives both
+        bias corrections from it, so the same launch is valid eagerly, inside a HIP-graph capture and on every replay -
+        the host uploads nothing per step and may run any number of steps ahead of the device."""
         self.step_count += 1
-        b1, b2 = self.betas
-        self._scal_host[0] = self.lr / (1.0 - b1 ** self.step_count)
-        self._scal_host[1] = math.sqrt(1.0 - b2 ** self.step_count)
-        self._scal_dev.copy_(self._scal_host, non_blocking=True)
-
-    def ensure_scalars(self):
-        if not hasattr(self, '_scal_host'):
-            self._scal_host = torch.zeros(2, dtype=torch.float32).pin_memory()
-            self._scal_dev = torch.zeros(2, dtype=torch.float32, device=self.flat_param.device)
+        for i in range(len(self.bucket_ranges)):
+            self.step_bucket(i, gscale)
 
     def step_captured(self, gscale=1.0):
-        """The Adam launch with scalars read from device memory (safe inside HIP-graph capture)."""
-        b1, b2 = self.betas
-        dev, st = lib.stream_args(self.flat_param)
-        lib.call('mmft_adam_step_dev', self.flat_param, self.flat_grad, self.m, self.v, self.n, self._scal_dev, float(b1),
-                 float(b2), float(self.eps), float(self.wd), float(gscale), dev, st)
+        """The same launch while a HIP graph is being captured: recording it takes no step."""
+        self.step(gscale)
+        self.step_count -= 1
+
+    def note_replay(self):
+        """Host mirror of the device counter after a graph replay that contains the Adam launch."""
+        self.step_count += 1
+
+    def device_step_count(self):
+        return int(self.state[0, 0].item())
 
 
 def _dense(t):

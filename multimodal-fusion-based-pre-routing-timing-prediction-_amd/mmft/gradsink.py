@@ -15,7 +15,37 @@ _epoch = [0]
 
 def attach(param, grad_view):
     """Route gradients of `param` (a leaf) into `grad_view`, a dense view with the parameter's shape and strides."""
-    param._mmft_sink = [grad_view, -1]
+    param._mmft_sink = [grad_view, -1, None]
+
+
+class Bucket:
+    """A group of sunk parameters whose gradients travel together (one all-reduce under data parallelism).
+    `on_complete(bucket)` is called from the backward pass - on whatever thread and stream the last producing
+    kernel was issued from - at the moment every member's gradient of the current step has been ISSUED."""
+
+    def __init__(self, name, params, on_complete=None):
+        self.name, self.on_complete = name, on_complete
+        self.members = [p._mmft_sink for p in params]
+        for rec in self.members:
+            rec[2] = self
+        self.pending, self.epoch = len(self.members), -1
+
+    def _delivered(self):
+        if self.epoch != _epoch[0]:
+            self.epoch, self.pending = _epoch[0], len(self.members)
+        self.pending -= 1
+        if self.pending == 0 and self.on_complete is not None:
+            self.on_complete(self)
+
+    def complete(self):
+        return self.epoch == _epoch[0] and self.pending == 0
+
+
+def _mark(sink):
+    """First gradient of the current step goes into `sink`."""
+    sink[1] = _epoch[0]
+    if sink[2] is not None:
+        sink[2]._delivered()
 
 
 def detach(param):
@@ -55,15 +85,15 @@ def deliver(sink, compute, shape=None):
     """
     if sink is None:
         return compute(None)
-    view, seen = sink
+    view, seen = sink[0], sink[1]
     mem, _ = _memory_order(view)
     if mem is None:
         return compute(None)
     if shape is not None:
         mem = mem.reshape(shape)                 # a view: mem is contiguous
     if seen != _epoch[0]:
-        sink[1] = _epoch[0]
         compute(mem)
+        _mark(sink)
     else:
         mem.add_(compute(None).reshape(mem.shape))
     return None
@@ -72,15 +102,17 @@ def deliver(sink, compute, shape=None):
 def deliver_pair(sink_a, sink_b, compute):
     """Two gradients from ONE kernel (weight and bias gradient of a Linear): compute(out_a, out_b) -> (a, b) in
     memory order, writing into the outs that are given.  Returns the pair the autograd Function must return."""
-    outs, late = [], []
+    outs, late, fresh_sinks = [], [], []
     for sink in (sink_a, sink_b):
         mem = _memory_order(sink[0])[0] if sink is not None else None
         if mem is not None and sink[1] != _epoch[0]:
-            sink[1] = _epoch[0]
+            fresh_sinks.append(sink)
             outs.append(mem); late.append(None)
         else:
             outs.append(None); late.append(mem)
     res = list(compute(outs[0], outs[1]))
+    for sink in fresh_sinks:                 # marked after the producing kernel has been issued
+        _mark(sink)
     for i in range(2):
         if outs[i] is not None:
             res[i] = None
@@ -96,6 +128,10 @@ def fresh(sink):
 
 
 def take(sink):
-    """Mark the sink written for this step and return its view (the caller's kernel stores into it)."""
-    sink[1] = _epoch[0]
+    """Return the sink's view for the caller's kernel to store into; the caller calls `taken(sink)` once that kernel
+    has been issued."""
     return sink[0]
+
+
+def taken(sink):
+    _mark(sink)

@@ -371,6 +371,28 @@ def scatter_add_rows(dst, idx, src):
     return dst
 
 
+def scatter_add_rows_sorted(dst, idx, order, src):
+    """dst[idx[t]] += src[t], bitwise reproducible with duplicates: `order` = stable argsort of idx (int32)."""
+    _rows2d(dst, 'dst'); _rows2d(src, 'src'); _idx(idx, 'idx', src.shape[0]); _idx(order, 'order', src.shape[0])
+    if src.shape[1] != dst.shape[1]:
+        raise ValueError('scatter_add_rows_sorted: width mismatch')
+    dev, st = lib.stream_args(dst)
+    lib.call('mmft_scatter_add_rows_sorted', dst, dst.stride(0), idx, order, idx.numel(), dst.shape[1], src,
+             src.stride(0), dev, st)
+    return dst
+
+
+def scatter_add_targets(dst, idx, src, order=None, unique=None):
+    """Endpoint-gradient scatter of the reverse sweep.  `order` given: deterministic sorted form.  `unique` True: the
+    caller knows there are no duplicates, one atomic add per element is then exact and order-free.  Otherwise the
+    stable order is derived on the device (two torch sort kernels)."""
+    if order is None and not unique and idx.numel() > 1:
+        order = torch.sort(idx.long(), stable=True)[1].to(torch.int32)
+    if order is None:
+        return scatter_add_rows(dst, idx, src)
+    return scatter_add_rows_sorted(dst, idx, order, src)
+
+
 # ------------------------------------------------------------------------------------------ CNN (NHWC)
 def is_nhwc(t):
     return t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous()

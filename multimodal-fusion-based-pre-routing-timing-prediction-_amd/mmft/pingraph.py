@@ -201,6 +201,35 @@ class PinGraph:
         self._level_cache[key] = (nodes, meta)
         return meta
 
+    def level_set_is_complete(self, level_nodes):
+        """True when the level lists are a complete, well-formed schedule of this graph: every node is in exactly one
+        level, every edge runs from a lower to a higher level, net in-edges enter odd levels only and cell in-edges
+        even levels >= 2 only (src/model.py:180-204).  Only then may the reverse sweep skip the zero fills of G / DA:
+        every row a pull reads is rewritten earlier in the same reverse sweep.  A partial schedule (fan-in cone,
+        truncated list) leaves consumers outside it, whose G / DA rows must read as zero.  Cached per list object."""
+        if any(torch.is_tensor(n) for n in level_nodes):
+            return False                                        # device-resident lists: not inspected, take the safe path
+        key = ('complete', tuple(id(n) for n in level_nodes), tuple(len(n) for n in level_nodes))
+        hit = self._level_cache.get(key)
+        if hit is not None:
+            return hit
+        lev = np.full(self._n, -1, dtype=np.int64)
+        ok, total = True, 0
+        for l, nodes in enumerate(level_nodes):
+            v = np.asarray(nodes, dtype=np.int64)
+            total += v.shape[0]
+            if v.size and (lev[v] >= 0).any():
+                ok = False
+            lev[v] = l
+        ok = ok and total == self._n and bool((lev >= 0).all())
+        if ok:
+            for et, parity in (('net', 1), ('cell', 0)):
+                s_, d_ = self._coo[et]
+                if s_.size and not bool(((lev[s_] < lev[d_]) & (lev[d_] % 2 == parity) & (lev[d_] >= 1)).all()):
+                    ok = False
+        self._level_cache[key] = ok
+        return ok
+
     # ------------------------------------------------------------------ construction helpers
     @staticmethod
     def from_synth(d, out_dim=None):

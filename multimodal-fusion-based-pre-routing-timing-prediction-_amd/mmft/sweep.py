@@ -55,6 +55,9 @@ class SweepState:
         self.token = None
         self.next_level = 0
         self.bwd_active = False
+        self.complete = False               # level lists = a complete schedule of the graph (whole-sweep entry)
+        self.target_order = None
+        self.targets_unique = None
 
     def _buf(self, name, width):
         b = self._bufs.get(name)
@@ -172,7 +175,7 @@ class LevelFn(torch.autograd.Function):
         st.begin_backward()
         if ctx.tix.numel() and gout is not None:
             go = gout if gout.is_contiguous() else gout.contiguous()
-            ops.scatter_add_rows(st.G, ctx.tix, go)
+            ops.scatter_add_targets(st.G, ctx.tix, go, unique=g.__dict__.get('targets_unique'))
         P = [_w(p) for p in st.params]
         (w1c, b1c, w2c, b2c, w1n, b1n, w2n, b2n, w1g, b1g, w2g, b2g) = P
         if rows.numel():
@@ -375,10 +378,18 @@ class SweepFn(torch.autograd.Function):
     def backward(ctx, gout):
         st, g = ctx.state, ctx.state.graph
         st.bwd_active = False
-        st.begin_backward(zero_da=False, zero_g=False)
+        # The fills of G / DA (2 x 268 MB per step at config B) may only be skipped when the level lists are a complete
+        # schedule of the graph: then every row a pull reads was rewritten earlier in this reverse sweep.  With a
+        # partial schedule (fan-in cone, truncated lists) consumers outside it keep rows from an earlier step - or
+        # uninitialised memory - so both buffers are zero-filled and the own-gradient flags are not used.
+        fast = st.complete
+        st.begin_backward(zero_da=not fast, zero_g=not fast)
+        own = st.tflag if fast else None
         if ctx.tix.numel():
-            ops.target_rows_begin(st.G, ctx.tix, st.tflag)
-            ops.scatter_add_rows(st.G, ctx.tix, gout if gout.is_contiguous() else gout.contiguous())
+            if fast:
+                ops.target_rows_begin(st.G, ctx.tix, st.tflag)
+            ops.scatter_add_targets(st.G, ctx.tix, gout if gout.is_contiguous() else gout.contiguous(),
+                                    order=st.target_order, unique=st.targets_unique)
         P = [_w(p) for p in st.params]
         w1g, w2g = P[8], P[10]
         out_net, out_cell, in_net_ptr = g.csr('out', 'net'), g.csr('out', 'cell'), g.out_net_weight()
@@ -388,21 +399,25 @@ class SweepFn(torch.autograd.Function):
             meta = st.level_meta[level_id] if st.level_meta else None
             spec = meta['range'] if (meta and meta['range']) else rows
             ops.level_bwd_pull(st.G, st.h, spec, out_net, in_net_ptr, out_cell, st.A, st.LSE, st.DA, relu=st.relu,
-                               alg_bytes=meta['bytes_pull'] if meta else 0, own=st.tflag)
+                               alg_bytes=meta['bytes_pull'] if meta else 0, own=own)
             if level_id % 2 == 0 and level_id > 0:
                 _cell_neigh_bwd(st, rows, w1g, w2g, keep_dhn=True)
         grads = _batched_param_grads(st, P, dhn_ready=True) if ctx.nparams else []
-        if ctx.tix.numel():
+        if ctx.tix.numel() and fast:
             ops.target_rows_end(ctx.tix, st.tflag)
         st.bwd_active = False
         return (None, None, None, *grads)
 
 
-def sweep_forward_all(conv, graph, level_nodes, targets):
+def sweep_forward_all(conv, graph, level_nodes, targets, target_order=None, targets_unique=None):
     """All levels of one sweep in one call. level_nodes: list (per level) of python int lists or device int32
-    tensors; targets: device int32 tensor (or list) of node ids whose embeddings are returned, in order."""
+    tensors; targets: device int32 tensor (or list) of node ids whose embeddings are returned, in order.
+    target_order: optional device int32 stable argsort of `targets` (the host has it for free when it packs a
+    step's endpoints); targets_unique: True when the caller knows that no endpoint is repeated."""
     st = SweepState(graph, conv)
     graph._sweep = st
+    st.complete = graph.level_set_is_complete(level_nodes)
+    st.target_order, st.targets_unique = target_order, targets_unique
     level_rows = [graph.level_rows(l, nodes, 'nodes') for l, nodes in enumerate(level_nodes)]
     st.level_meta = [graph.level_meta(l, nodes, st.D) if not torch.is_tensor(nodes) else None
                      for l, nodes in enumerate(level_nodes)]

@@ -38,11 +38,22 @@ def build_models(map_size=128, out_dim=128, cell_feat_dim=36, net_feat_dim=2, cn
 def trainable_parameters(pmodel, cnn):
     """Parameters that receive gradients (fc_net_drive / fc_attn2 are unused in forward: torch's Adam skips
     them because their .grad stays None, src/model.py:52-54)."""
+    return [p for _, ps in parameter_buckets(pmodel, cnn) for p in ps]
+
+
+def parameter_buckets(pmodel, cnn):
+    """The trainable parameters grouped by WHEN their gradients exist in the backward pass: the fusion head (fcn,
+    mlp_fuse, mlp_alpha: ready right after the head's backward, 2.27 M of 2.89 M parameters at defaults) and the rest
+    (GNN: end of the reverse sweep; CNN: end of the U-Net backward).  Under data parallelism each group is one
+    all-reduce (mmft.dist.GradReducer)."""
     skip = ('gnn.fc_net_drive.', 'gnn.fc_attn2.')
-    ps = [p for n, p in pmodel.named_parameters() if not n.startswith(skip)]
+    named = [(n, p) for n, p in pmodel.named_parameters() if not n.startswith(skip)]
+    head = [p for n, p in named if not n.startswith(('gnn.', 'cnn.'))]
+    rest = [p for n, p in named if n.startswith(('gnn.', 'cnn.'))]
     if cnn is not None:
-        ps += list(cnn.parameters())
-    return ps
+        seen = {id(p) for p in rest}
+        rest += [p for p in cnn.parameters() if id(p) not in seen]
+    return [('head', head), ('gnn+cnn', rest)]
 
 
 class DesignBatch:
@@ -111,16 +122,47 @@ class DesignBatch:
         counts = np.bincount(lv, minlength=self.L)
         first, nxt = batch_links(gp, self.path2level.shape[0])
         T = gp.shape[0]
-        packed = np.concatenate([ends, gp, self.path2design[gp] * self.P, lv, nxt, first]).astype(np.int32)
+        eorder = np.argsort(ends, kind='stable')       # batch rows grouped by endpoint: deterministic gradient scatter
+        self.ends_unique = bool(T < 2 or (np.diff(ends[eorder]) != 0).all())
+        packed = np.concatenate([ends, gp, self.path2design[gp] * self.P, lv, nxt, eorder, first]).astype(np.int32)
         if static is not None:
             if static.numel() != packed.shape[0]:
                 raise ValueError('graph replay needs a constant number of sampled paths per step')
-            static.copy_(torch.from_numpy(packed), non_blocking=True)
+            static.copy_(self._stage(packed), non_blocking=True)
+            self._stage_done()
             dev = static
         else:
             dev = torch.from_numpy(packed).to(self.device)
-        self.links = (dev[5 * T:], dev[4 * T:5 * T])
+        self.links = (dev[6 * T:], dev[4 * T:5 * T])
+        self.end_order = dev[5 * T:6 * T]
         return dev[0:T], dev[T:2 * T], dev[2 * T:3 * T], counts, self.old_of_new[ends], dev[3 * T:4 * T]
+
+    STAGING_SLOTS = 4
+
+    def _stage(self, packed):
+        """Copy one step's packed indices into the next of STAGING_SLOTS pinned host buffers.  A slot is reused only
+        after the H2D copy that last read it has executed (its event), so the host may run up to STAGING_SLOTS - 1
+        steps ahead of the device without overwriting indices that are still to be copied; the copy itself is a true
+        asynchronous DMA (pinned source), not a staged pageable copy that stalls the host."""
+        n = packed.shape[0]
+        st = self.__dict__.get('_staging')
+        if st is None or st['n'] != n:
+            st = dict(n=n, i=0, bufs=[torch.empty(n, dtype=torch.int32).pin_memory() for _ in range(self.STAGING_SLOTS)],
+                      events=[None] * self.STAGING_SLOTS)
+            self._staging = st
+        k = st['i'] % self.STAGING_SLOTS
+        if st['events'][k] is not None:
+            st['events'][k].synchronize()
+        st['bufs'][k].numpy()[:] = packed
+        return st['bufs'][k]
+
+    def _stage_done(self):
+        st = self._staging
+        k = st['i'] % self.STAGING_SLOTS
+        ev = st['events'][k] or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        st['events'][k] = ev
+        st['i'] += 1
 
 
 class TrainStep:
@@ -140,10 +182,17 @@ class TrainStep:
             cnn.set_per_sample_stats(True)      # per-image statistics == the reference's one-image batches, any B
         params = trainable_parameters(pmodel, cnn)
         self.fused = fused_optimizer
+        self.reducer = None
         if not with_optimizer:                  # evaluation-only harness (mmft.evaluate.validate): shares the modules
             self.optim = None
         elif fused_optimizer:
-            self.optim = FlatAdam(params, lr=lr, weight_decay=weight_decay)
+            if world_size > 1:
+                # data parallel: one flat range per gradient bucket, reduced as soon as its gradients exist
+                from .dist import GradReducer
+                self.optim = FlatAdam(params, lr=lr, weight_decay=weight_decay, buckets=parameter_buckets(pmodel, cnn))
+                self.reducer = GradReducer(self.optim, world_size, device, side_stream=self.side)
+            else:
+                self.optim = FlatAdam(params, lr=lr, weight_decay=weight_decay)
         else:
             self.optim = torch.optim.Adam(params, lr, weight_decay=weight_decay)     # src/train.py:431-435
         pmodel.train()
@@ -169,9 +218,10 @@ class TrainStep:
                 if self.overlap:
                     self.side.wait_stream(cur)
                     with torch.cuda.stream(self.side):
-                        h_gnn = _sweep.sweep_forward_all(self.pmodel.gnn, g, b.level_nodes, ends_d)
+                        h_gnn = _sweep.sweep_forward_all(self.pmodel.gnn, g, b.level_nodes, ends_d,
+                                                         target_order=b.end_order)
                 else:
-                    h_gnn = _sweep.sweep_forward_all(self.pmodel.gnn, g, b.level_nodes, ends_d)
+                    h_gnn = _sweep.sweep_forward_all(self.pmodel.gnn, g, b.level_nodes, ends_d, target_order=b.end_order)
             feat = self.cnn(b.images).reshape(b.B, -1) if self.cnn is not None else None
             pm = MaskedPathMap(b.masks, paths_d, feat, foff_d if b.B > 1 else None, *b.links) \
                 if feat is not None else None
@@ -182,6 +232,7 @@ class TrainStep:
                 h_gnn.record_stream(cur)
             return self.pmodel.fuse_heads(h_gnn, pm, lv_d, b.L, h_cnn=h_cnn), ends_d, ends_h
         feat = self.cnn(b.images).reshape(b.B, -1) if self.cnn is not None else None      # src/train.py:465,562
+        g.targets_unique = b.ends_unique      # host knowledge: no repeated endpoint -> one exact atomic add per element
         hats, pos = [], 0
         for level_id in range(b.L):                                                       # src/train.py:490-511
             k = int(counts[level_id])
@@ -197,16 +248,27 @@ class TrainStep:
 
     def step(self, path_ids_per_design):
         """One mini-batch: forward, MSE on arrival time, backward, (all-reduce,) Adam.
-        Returns (loss tensor, predictions, target node ids)."""
+        Returns (loss tensor, predictions, target node ids); `self.last_ends` holds the endpoints' device-side
+        (renumbered) node ids, the index space of `self.batch.arrival` / `.required`."""
         hats, ends_d, ends_h = self.forward(path_ids_per_design)
+        self.last_ends = ends_d
         arrival = self.batch.arrival[ends_d.long()].squeeze(-1)                            # src/train.py:520-522
         loss = mse_loss(hats, arrival)
         self.optim.zero_grad()
-        loss.backward()
-        if self.world_size > 1:
+        if self.reducer is not None:
+            self.reducer.begin()
+            loss.backward()
+            self.reducer.finish()            # buckets not yet reduced; compute stream waits for the last Adam
+        elif self.world_size > 1:
             from .dist import allreduce_sum_
-            self.optim.step(gscale=allreduce_sum_(self.optim.flat_grad, self.world_size))
+            loss.backward()
+            grads = [p.grad for p in self.optim.param_groups[0]['params'] if p.grad is not None]
+            for g in grads:                  # torch.optim.Adam route: per-tensor all-reduce, mean of the ranks
+                allreduce_sum_(g, self.world_size)
+                g.mul_(1.0 / self.world_size)
+            self.optim.step()
         else:
+            loss.backward()
             self.optim.step()
         return loss.detach(), hats.detach(), ends_h.tolist()
 
@@ -214,10 +276,12 @@ class TrainStep:
 class GraphedTrainStep:
     """The whole mini-batch (forward, MSE, backward, fused Adam) captured ONCE as a HIP graph and replayed per
     step: the ~550 kernel launches of a step then cost no host time.  Per step the host only packs the sampled
-    endpoints into one pinned int32 buffer (one H2D copy into a static device buffer) and uploads Adam's two
-    bias-correction scalars.  Requires a constant number of sampled paths per step.  Under data parallelism the
-    graph holds forward + backward only; the RCCL all-reduce of the flat gradient and the fused Adam launch follow
-    the replay eagerly (two launches), so no collective is ever captured."""
+    endpoints into a pinned int32 staging slot (one asynchronous H2D copy into a static device buffer); Adam's step
+    counter lives on the device, so nothing else is uploaded.  Requires a constant number of sampled paths per step.  Under data parallelism the
+    graph holds forward + backward only: event-record nodes inside it tell the communication stream when a gradient
+    bucket is complete, and each bucket's RCCL all-reduce + Adam launch are issued eagerly behind the replay
+    (mmft.dist.GradReducer), so no collective is ever captured yet the head bucket is reduced under the rest of the
+    backward."""
 
     def __init__(self, ts, example_path_ids, warmup=3):
         if not ts.fused or ts.mode != 'sweep':
@@ -245,10 +309,9 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         sel = b.select(example_path_ids)
         T = sel[0].numel()
-        self.static_idx = torch.zeros(5 * T + b.path2level.shape[0], dtype=torch.int32, device=ts.device)
+        self.static_idx = torch.zeros(6 * T + b.path2level.shape[0], dtype=torch.int32, device=ts.device)
         self.T = T
         sel = b.select(example_path_ids, static=self.static_idx)
-        ts.optim.ensure_scalars()          # buffers only: capturing records the launch, it does not take a step
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog thread may query events while this thread captures
@@ -257,20 +320,25 @@ class GraphedTrainStep:
             arrival = b.arrival[ends_d.long()].squeeze(-1)
             loss = mse_loss(hats, arrival)
             ts.optim.zero_grad()
-            loss.backward()
-            if ts.world_size == 1:
+            if ts.reducer is not None:
+                ts.reducer.begin(capturing=True)     # bucket-complete events become event-record nodes of the graph
+                loss.backward()
+                ts.reducer.end_capture()
+            else:
+                loss.backward()
                 ts.optim.step_captured()
             self.loss, self.hats = loss.detach(), hats.detach()
         torch.cuda.synchronize()
 
     def step(self, path_ids_per_design):
-        b = self.ts.batch
+        """Host side of a step: pack the sampled endpoints (pinned staging slot -> one async H2D copy), replay.  No
+        host synchronisation: the host may run ahead of the device (the staging slots bound it)."""
+        ts, b = self.ts, self.ts.batch
         sel = b.select(path_ids_per_design, static=self.static_idx)
-        if self.ts.world_size == 1:
-            self.ts.optim.prepare_step()
-            self.graph.replay()
+        ts.last_ends = sel[0]
+        self.graph.replay()
+        if ts.reducer is not None:
+            ts.reducer.after_replay()        # per bucket: wait for its in-graph event, all-reduce, Adam
         else:
-            from .dist import allreduce_sum_
-            self.graph.replay()
-            self.ts.optim.step(gscale=allreduce_sum_(self.ts.optim.flat_grad, self.ts.world_size))
+            ts.optim.note_replay()
         return self.loss, self.hats, sel[4].tolist()

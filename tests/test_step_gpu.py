@@ -1,0 +1,302 @@
+"""Train-step plumbing on the GPU (round 2): device-side Adam step counter under un-synchronised graph replay, the
+deterministic endpoint-gradient scatter, partial level schedules (fan-in cone) on fresh / stale sweep buffers, and the
+data-parallel step (two ranks sharing one GPU over gloo) against the fp64 oracle's mean-of-per-design gradients."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import restatement as R
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'multimodal-fusion-based-pre-routing-timing-prediction-_amd')
+
+
+def test_adam_counter_lives_on_the_device(dev):
+    """mmft_adam_step_counted: bias corrections derived in the kernel from the device-side step counter equal
+    torch.optim.Adam's for 40 steps, with the launches issued back to back (no host sync between them)."""
+    from mmft.fusion import FlatAdam
+    torch.manual_seed(5)
+    shapes = [(301, 7), (64,), (3,)]
+    ps = [torch.randn(s, device=dev).requires_grad_(True) for s in shapes]
+    qs = [p.detach().clone().requires_grad_(True) for p in ps]
+    ref = torch.optim.Adam(ps, 1e-3)
+    mine = FlatAdam(qs, lr=1e-3, buckets=[('a', qs[:1]), ('b', qs[1:])])
+    gs = [[torch.randn(s, device=dev) for s in shapes] for _ in range(40)]
+    for g3 in gs:
+        for p, g in zip(ps, g3):
+            p.grad = g.clone()
+        ref.step()
+    for g3 in gs:                       # all 40 steps enqueued without a sync; the gradients are staged on the stream
+        for q, g in zip(qs, g3):
+            q.grad.copy_(g)
+        mine.step()
+    assert mine.step_count == 40 and mine.state[:, 0].tolist() == [40, 40] and mine.state[:, 1].tolist() == [0, 0]
+    for p, q in zip(ps, qs):
+        assert rel_err(q, p) < 2e-6
+
+
+def test_graphed_steps_without_host_sync_equal_eager(dev):
+    """60 replays of the captured step with NO host synchronisation in between (the host runs ahead of the device,
+    bounded by the pinned staging slots) end with the parameters of 60 eager steps that sync every step."""
+    from mmft.synth import synth_design
+    from mmft.train import build_models, TrainStep, GraphedTrainStep
+    designs = [synth_design(N=2048, L=12, tile=32, seed=310 + i, end_frac=0.25) for i in range(2)]
+    rng = np.random.default_rng(19)
+    batches = [[rng.permutation(d.num_paths)[:32].tolist() for d in designs] for _ in range(60)]
+    out = {}
+    for kind in ('eager', 'graph'):
+        pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=11)
+        ts = TrainStep(pmodel, cnn, designs, dev)
+        if kind == 'graph':
+            stepper = GraphedTrainStep(ts, batches[0], warmup=0)
+            for ids in batches:
+                stepper.step(ids)                               # no float(loss), no synchronize
+            torch.cuda.synchronize()
+            assert ts.optim.device_step_count() == 60 == ts.optim.step_count
+        else:
+            ts.forward(batches[0])                              # the capture's dry run also advances BN running stats
+            for ids in batches:
+                loss, _, _ = ts.step(ids)
+                float(loss)
+        out[kind] = {k: v.detach().clone() for k, v in list(pmodel.state_dict().items()) + list(cnn.state_dict().items())
+                     if v.dtype.is_floating_point}
+    for k in out['eager']:
+        assert rel_err(out['graph'][k], out['eager'][k]) < 5e-4, k
+
+
+def test_endpoint_scatter_with_duplicates_is_deterministic(dev):
+    """>= 3 copies of an endpoint (os_rate oversampling, src/train.py:377-380): the sorted scatter sums them in batch
+    order - equal to the fp64 sum and bitwise equal from run to run (the atomic form is order dependent)."""
+    from mmft import ops
+    g = torch.Generator().manual_seed(2)
+    N, D, T = 500, 128, 4000
+    idx = torch.randint(0, 40, (T,), generator=g).to(torch.int32)           # ~100 copies of each destination
+    src = torch.randn(T, D, generator=g)
+    base = torch.randn(N, D, generator=g)
+    ref = base.double().index_add(0, idx.long(), src.double())
+    order = torch.sort(idx.long(), stable=True)[1].to(torch.int32)
+    outs = []
+    for _ in range(3):
+        dst = base.clone().to(dev)
+        ops.scatter_add_rows_sorted(dst, idx.to(dev), order.to(dev), src.to(dev))
+        outs.append(dst.cpu())
+    assert rel_err(outs[0], ref) < 1e-6
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    dst = base.clone().to(dev)
+    ops.scatter_add_targets(dst, idx.to(dev), src.to(dev))                  # order derived on the device
+    assert torch.equal(dst.cpu(), outs[0])
+
+
+def _oracle_gnn_grads(pm_state, d, old_ends, levels_old):
+    """fp64 gradients of sum(h[ends]^2) through the oracle's level sweep (original node ids)."""
+    p = {k: v.detach().double().clone().requires_grad_(True) for k, v in pm_state.items() if k.startswith('gnn.')}
+    csr = R.design_csr(d)
+    h = torch.zeros((d.N, 128), dtype=torch.float64)
+    cf, nf = torch.from_numpy(d.cell_feat).double(), torch.from_numpy(d.net_feat).double()
+    for l, nodes in enumerate(levels_old):
+        h, _ = R.pathconv_level(p, 'gnn.', csr, h, cf, nf, nodes, [], l)
+    out = h[torch.as_tensor(old_ends)]
+    (out * out).sum().backward()
+    return out.detach(), {k[4:]: v.grad for k, v in p.items() if v.grad is not None}
+
+
+def test_partial_schedule_on_fresh_and_stale_buffers_vs_oracle(dev):
+    """A fan-in-cone sweep (level lists that do NOT cover the graph) has consumers outside the cone: their G / DA rows
+    must read as zero.  Run it FIRST on buffers filled with garbage, and again after a full sweep with other endpoints
+    left its own gradients behind; both times the parameter gradients equal the fp64 oracle's."""
+    from mmft import prep
+    from mmft import sweep as S
+    from mmft.synth import synth_design
+    from mmft.train import build_models, DesignBatch
+    d = synth_design(N=6000, L=16, tile=32, seed=78, end_frac=0.2)
+    b = DesignBatch([d], dev)
+    pmodel, _ = build_models(map_size=d.map_size, device=dev, seed=6)
+    pm_state = {k: v.detach().cpu() for k, v in pmodel.state_dict().items()}
+    g = b.graph
+    ends, _, _, _, ends_old, _ = b.select([[3, 11, 11, 40, 41]])
+    in_csrs = [g.csr('in', 'net'), g.csr('in', 'cell')]
+    cone = prep.fanin_cone(in_csrs, [torch.tensor(l, dtype=torch.int32, device=dev) for l in b.level_nodes], ends)
+    assert sum(c.numel() for c in cone) < b.N                               # really partial
+    ref_out, ref_grads = _oracle_gnn_grads(pm_state, d, ends_old, [lv.tolist() for lv in d.levels])
+
+    def run(levels, targets):
+        for p in pmodel.gnn.parameters():
+            p.grad = None
+        h = S.sweep_forward_all(pmodel.gnn, g, levels, targets)
+        (h * h).sum().backward()
+        return h.detach(), {k: p.grad.clone() for k, p in pmodel.gnn.named_parameters() if p.grad is not None}
+
+    g.ndata['h'] = torch.zeros((b.N, 128), dtype=torch.float32, device=dev)
+    # "uninitialised" sweep buffers: NaN in every row the cone does not rewrite
+    bufs = g.__dict__.setdefault('_sweep_bufs', {})
+    bufs['key'] = (b.N, 128, 256, g.ndata['h'].device)
+    for name, width in (('G', 128), ('DA', 128)):
+        bufs[name] = torch.full((b.N, width), float('nan'), dtype=torch.float32, device=dev)
+    out1, grads1 = run(cone, ends)                                          # cone FIRST, on garbage
+    assert rel_err(out1, ref_out) < 1e-5
+    assert grads1.keys() == ref_grads.keys()
+    for k in ref_grads:
+        assert rel_err(grads1[k], ref_grads[k]) < 1e-4, k
+    other, _, _, _, _, _ = b.select([[0, 1, 2, 5, 8, 13, 21, 34, 55]])
+    run(b.level_nodes, other)                                               # full sweep, other endpoints: stale G / DA rows
+    out2, grads2 = run(cone, ends)
+    for k in ref_grads:
+        assert rel_err(grads2[k], ref_grads[k]) < 1e-4, k
+        assert torch.equal(grads2[k], grads1[k]), k                         # and bitwise reproducible
+
+
+# ------------------------------------------------------------------------------------------------ data parallel
+def _dp_worker(rank, world, port, out_dir):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)                                # both ranks share the one GPU: rehearsal over gloo
+    dev = torch.device('cuda:0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from mmft.dist import design_seeds
+    from mmft.synth import synth_design
+    from mmft.train import build_models, TrainStep, GraphedTrainStep
+    d = synth_design(N=2048, L=12, tile=32, seed=design_seeds(rank, 1)[0], end_frac=0.25)
+    pmodel, cnn = build_models(map_size=d.map_size, device=dev, seed=21)       # identical parameters on every rank
+    ts = TrainStep(pmodel, cnn, [d], dev, world_size=world)
+    rng = np.random.default_rng(100 + rank)
+    batches = [[rng.permutation(d.num_paths)[:24].tolist()] for _ in range(5)]
+    names = [n for n, _ in list(pmodel.named_parameters()) + [('cnn.' + k, v) for k, v in cnn.named_parameters()]]
+    out = dict(batches=batches, names=names)
+    ts.step(batches[0])                                     # eager step: bucketed all-reduce + per-bucket Adam
+    torch.cuda.synchronize()
+    out['grad1'] = {n: (p.grad.detach().cpu().clone() / world if p.grad is not None else None)
+                    for n, p in list(pmodel.named_parameters()) + [('cnn.' + k, v) for k, v in cnn.named_parameters()]}
+    ts.step(batches[1])
+    gs = GraphedTrainStep(ts, batches[2], warmup=0)         # replayed forward + backward, reducer behind every replay
+    for ids in batches[2:]:
+        gs.step(ids)
+    torch.cuda.synchronize()
+    out['steps'] = ts.optim.step_count
+    out['dev_steps'] = ts.optim.state[:, 0].tolist()
+    out['params'] = {n: p.detach().cpu().clone()
+                     for n, p in list(pmodel.named_parameters()) + [('cnn.' + k, v) for k, v in cnn.named_parameters()]}
+    torch.save(out, os.path.join(out_dir, f'r{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_share_one_gpu(dev, tmp_path):
+    """TrainStep(world_size=2) + GraphedTrainStep on two ranks (gloo, one GPU): the reduced flat gradient equals the
+    fp64 oracle's mean of the per-design gradients, both ranks end with identical parameters, and those follow the
+    oracle's Adam on the averaged loss for 5 steps."""
+    import torch.multiprocessing as mp
+    from mmft.dist import design_seeds
+    from mmft.synth import synth_design
+    from mmft.train import build_models
+    port = 29600 + (os.getpid() % 2000)
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(os.path.join(tmp_path, f'r{k}.pt'), weights_only=False) for k in range(2)]
+    assert r[0]['steps'] == r[1]['steps'] == 5 and r[0]['dev_steps'] == [5, 5]
+    for n in r[0]['params']:
+        assert torch.equal(r[0]['params'][n], r[1]['params'][n]), n          # replicas stay bitwise identical
+    # fp64 oracle: one parameter set, loss = mean of the two ranks' losses, torch Adam
+    ds = [synth_design(N=2048, L=12, tile=32, seed=design_seeds(k, 1)[0], end_frac=0.25) for k in range(2)]
+    pmodel, cnn = build_models(map_size=ds[0].map_size, device='cpu', seed=21)
+    orc = R.OracleTrainer({k: v.clone() for k, v in pmodel.state_dict().items()},
+                          {k: v.clone() for k, v in cnn.state_dict().items()}, dtype=torch.float64)
+    csrs = [R.design_csr(d) for d in ds]
+
+    def oracle_step(i):
+        orc.optim.zero_grad()
+        loss = 0
+        for k in range(2):
+            # each rank has its own copy of the BatchNorm buffers; they never enter the arithmetic (train mode)
+            hats, tl, _ = R.sweep_forward(orc.pm, orc.pc, ds[k], csrs[k], r[k]['batches'][i][0], update_running=False,
+                                          dtype=torch.float64)
+            arr = torch.from_numpy(ds[k].arrival_time).double()[torch.tensor(tl)].squeeze(-1)
+            loss = loss + torch.nn.functional.mse_loss(hats, arr) / 2
+        loss.backward()
+    oracle_step(0)
+    for n, gref in r[0]['grad1'].items():
+        o = orc.pc[n[4:]] if n.startswith('cnn.') else orc.pm[n]
+        if o.grad is None:
+            assert gref is None or float(gref.abs().max()) == 0.0, n
+        else:
+            assert rel_err(gref, o.grad) < 1e-4, n                          # reduced gradient = mean over the ranks
+            assert torch.equal(gref, r[1]['grad1'][n]), n
+    orc.optim.step()
+    for i in range(1, 5):
+        oracle_step(i)
+        orc.optim.step()
+    bad = tot = 0
+    for n, p in r[0]['params'].items():
+        o = orc.pc[n[4:]] if n.startswith('cnn.') else orc.pm[n]
+        diff = (p.double() - o.detach()).abs()
+        bad += int((diff > 2e-4).sum())         # an Adam step moves a weight by ~lr = 1e-3 whatever the gradient's size:
+        tot += diff.numel()                     # only weights whose gradient is ~0 (sign of noise) may differ
+    assert bad <= 1e-3 * tot, (bad, tot)
+
+
+def test_bench_self_launches_its_ranks(dev):
+    """`python bench.py --gpus 2` without torchrun: the process starts the two ranks itself before touching the GPU
+    (here rehearsed over gloo, both ranks on the one GPU) and rank 0 prints the single JSON line with n_gpus = 2."""
+    env = dict(os.environ, MMFT_DIST_BACKEND='gloo')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--designs', '1',
+           '--nodes', '4096', '--levels', '16', '--tile', '64', '--batch-paths', '64', '--no-cpu-baseline']
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['value'] > 0
+    assert abs(j['value'] - 2 * 1 * 3 / (j['ms_per_step'] * 3 / 1e3)) / j['value'] < 1e-6      # whole-job designs / s
+
+
+def test_in_graph_event_orders_the_communication_stream(dev):
+    """What GradReducer relies on under graph replay: an event recorded by an event-record node INSIDE a captured graph
+    (torch.cuda.Event(external=True)) orders a wait issued on another stream after the replay - and that stream runs
+    while the rest of the graph is still executing."""
+    n = 1 << 22
+    x = torch.zeros(n, device=dev)
+    big = torch.randn(4096, 4096, device=dev)
+    sink = torch.empty_like(big)
+    counter = torch.zeros(1, device=dev)
+    ev = torch.cuda.Event(external=True)
+    side = torch.cuda.Stream(device=dev)
+    warm = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(warm):
+        torch.mm(big, big, out=sink)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        counter += 1
+        x.copy_(counter.expand(n))                  # "gradient bucket complete"
+        ev.record(torch.cuda.current_stream(dev))
+        for _ in range(6):                          # the rest of the backward: a few ms of work
+            torch.mm(big, big, out=sink)
+    ys = torch.zeros(20, n // 1024, device=dev)
+    t_side, t_main = [], []
+    for i in range(20):
+        g.replay()
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            ys[i].copy_(x[::1024])
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(side)
+        e2 = torch.cuda.Event(enable_timing=True)
+        e2.record(torch.cuda.current_stream(dev))
+        torch.cuda.current_stream(dev).wait_stream(side)          # the next replay overwrites x
+        t_side.append(e1)
+        t_main.append(e2)
+    torch.cuda.synchronize()
+    want = torch.arange(1, 21, device=dev, dtype=torch.float32)[:, None].expand_as(ys)
+    assert torch.equal(ys, want), 'the side stream did not wait for the in-graph event'
+    lead = [e1.elapsed_time(e2) for e1, e2 in zip(t_side, t_main)]          # ms by which the side copy finished earlier
+    assert np.median(lead) > 0.2, lead

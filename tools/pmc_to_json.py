@@ -1,12 +1,17 @@
-"""rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (separate runs, CSV) -> profiles/r01_pmc_hbm_traffic.json.
+"""rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (separate runs, CSV) -> profiles/r02_pmc_hbm_traffic.json.
 
     python tools/pmc_to_json.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [steps]
 Per kernel name: launches, FETCH_SIZE * 1024 * 2 (KiB units; gfx950 reports half the bytes of wide coalesced reads,
-MI355X_MICROARCH.md "HBM"), WRITE_SIZE * 1024, and their sum per launch - what bench.py reports as roofline.traffic."""
+MI355X_MICROARCH.md "HBM"), WRITE_SIZE * 1024, and their sum per launch - what bench.py reports as roofline.traffic.
+The table is stamped with the fingerprint of the kernel sources of THIS tree (bench.csrc_fingerprint): run it on the
+tree the passes were taken on; bench.py reports traffic = null when the stamp does not match."""
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(path, counter):
@@ -33,8 +38,11 @@ def main():
         f = ft[k] * 1024.0 * 2.0 / n
         w = wt.get(k, 0.0) * 1024.0 / max(wc.get(k, n), 1)
         table[k] = dict(launches=n, fetch_bytes_per_launch_x2=f, write_bytes_per_launch=w, hbm_bytes_per_launch=f + w)
+    from bench import csrc_fingerprint
+    table['__stamp__'] = dict(csrc_sha256=csrc_fingerprint(), note='kernel sources the PMC passes were taken on')
     json.dump(table, open(out, 'w'), indent=0)
-    for k, v in sorted(table.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:12]:
+    rows = [(k, v) for k, v in table.items() if k != '__stamp__']
+    for k, v in sorted(rows, key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:12]:
         print(f"{k[:70]:70s} {v['launches']:5d} launches  {v['hbm_bytes_per_launch'] / 1e6:9.2f} MB/launch")
 
 
