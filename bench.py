@@ -41,6 +41,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_MFMA_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA, dense
+PEAK_MFMA_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: bf16 MFMA, dense (the 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 
 
@@ -48,8 +49,13 @@ def log(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
 
+HISTORY = []        # every endpoint batch of the run, in order (the bf16 run is replayed in fp32 for the MAE drift)
+
+
 def sample_paths(designs, batch_paths, rng):
-    return [rng.permutation(d.num_paths)[:min(batch_paths, d.num_paths)] for d in designs]
+    ids = [rng.permutation(d.num_paths)[:min(batch_paths, d.num_paths)] for d in designs]
+    HISTORY.append(ids)
+    return ids
 
 
 def _norm_kernel(name):
@@ -182,6 +188,7 @@ def main():
                     help='f32: exact fp32 MFMA everywhere (the 1e-4 parity mode); bf16: bf16 operands / fp32 accumulate '
                          'on the MFMA-bound contractions (BASELINE config B names bf16)')
     ap.add_argument('--cpu-steps', type=int, default=10)
+    ap.add_argument('--no-drift', action='store_true', help='bf16: skip the fp32 replay of the schedule (MAE drift)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -210,6 +217,7 @@ def main():
     from mmft.synth import synth_design
     from mmft.train import build_models, TrainStep
     from mmft import lib
+    lib.set_math_mode(args.dtype)
 
     from mmft.dist import design_seeds
     designs = [synth_design(N=args.nodes, L=args.levels, tile=args.tile, seed=sd, fanin=args.fanin)
@@ -283,8 +291,13 @@ def main():
         per_launch_ms = top['ms'] / top['launches']
         if top['flops'] > 0:
             ach = top['flops'] / (top['ms'] * 1e-3) / 1e12
-            roofline = dict(bound='mfma', achieved=ach, peak=PEAK_MFMA_F32_TFLOPS, unit='TFLOP/s',
-                            frac=ach / PEAK_MFMA_F32_TFLOPS, traffic=None)
+            peak = PEAK_MFMA_BF16_TFLOPS if (args.dtype == 'bf16' and 'bf16' in top['name']) else PEAK_MFMA_F32_TFLOPS
+            roofline = dict(bound='mfma', achieved=ach, peak=peak, unit='TFLOP/s', frac=ach / peak, traffic=None)
+            # a bf16 contraction fed from fp32 tensors is bound by its operand bytes long before the matrix pipe:
+            # report the HBM view of the same launch beside it
+            if top['bytes'] > 0:
+                gbs = top['bytes'] / (top['ms'] * 1e-3) / 1e9
+                roofline['hbm_view'] = dict(achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS)
         else:
             ach = top['bytes'] / (top['ms'] * 1e-3) / 1e9
             roofline = dict(bound='hbm', achieved=ach, peak=PEAK_HBM_GBS, unit='GB/s', frac=ach / PEAK_HBM_GBS,
@@ -306,6 +319,27 @@ def main():
         heldout_mae = validate(ev)
         log(f"held-out design: slack MAE {heldout_mae['endpoint_slack_mae']:.4f}, R2 {heldout_mae['r2']:.4f}")
 
+    # bf16 mode: the same schedule (same init, same endpoint batches in the same order) trained with exact fp32
+    # arithmetic, evaluated on the same held-out design -> drift of the accuracy half of the metric
+    f32_ref = None
+    if rank == 0 and world == 1 and args.dtype == 'bf16' and heldout_mae is not None and graphed and not args.no_drift:
+        log('replaying the schedule in fp32 for the held-out MAE drift')
+        from mmft.train import GraphedTrainStep
+        lib.set_math_mode('f32')
+        pm2, cnn2 = build_models(map_size=designs[0].map_size, device=dev, seed=9294)
+        pm2.load_state_dict(pm_state)
+        cnn2.load_state_dict(pc_state)
+        ts2 = TrainStep(pm2, cnn2, designs, dev, world_size=1, mode=args.mode, overlap=not args.no_overlap)
+        gs2 = GraphedTrainStep(ts2, HISTORY[0])
+        for ids in HISTORY[1:]:
+            gs2.step(ids)
+        torch.cuda.synchronize()
+        ev2 = TrainStep(pm2, cnn2, [held], dev, mode=args.mode, overlap=False, with_optimizer=False)
+        f32_ref = validate(ev2)
+        lib.set_math_mode(args.dtype)
+        log(f"fp32 replay ({ts2.optim.step_count} steps): held-out slack MAE {f32_ref['endpoint_slack_mae']:.4f} "
+            f"(bf16 run: {heldout_mae['endpoint_slack_mae']:.4f})")
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log('timing the CPU oracle (bounded sample)')
@@ -325,11 +359,12 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': args.dtype,
             'data': 'synthetic',
             'config': {
                 'workload': f'{"config B" if (args.designs, args.nodes, args.levels, args.tile) == (8, 65536, 64, 256) else "custom"}: {args.designs} designs/step/GPU, {args.nodes}-node netlist, {args.levels} levels, '
-                            f'{args.tile}x{args.tile} tile, {args.batch_paths} endpoints/design, UNet(max), fp32',
+                            f'{args.tile}x{args.tile} tile, {args.batch_paths} endpoints/design, UNet(max), '
+                            + ('fp32' if args.dtype == 'f32' else 'bf16 operands / fp32 accumulate on the MFMA-bound contractions (tensors in HBM fp32)'),
                 'designs_per_step_per_gpu': args.designs, 'nodes': args.nodes, 'levels': args.levels,
                 'tile': args.tile, 'endpoints_per_design': args.batch_paths,
                 'parallelism': f'dp{world} (designs sharded, one all-reduce of the flat gradient per step)',
@@ -342,6 +377,10 @@ def main():
             'train_mae_last_step': mae,
             'heldout_eval': dict(steps_trained=ts.optim.step_count, **{k: heldout_mae[k] for k in
                                  ('endpoint_slack_mae', 'r2', 'loss', 'f1', 'n')}) if heldout_mae else None,
+            'heldout_eval_f32_same_schedule': dict(steps_trained=ts2.optim.step_count, endpoint_slack_mae=f32_ref['endpoint_slack_mae'],
+                                                   r2=f32_ref['r2'],
+                                                   mae_drift=heldout_mae['endpoint_slack_mae'] - f32_ref['endpoint_slack_mae'])
+            if f32_ref else None,
             'loss_last_step': float(loss),
             'roofline': roofline,
             'cpu_baseline': cpu,

@@ -32,6 +32,16 @@ extern "C" {
 
 int mmft_version(void);
 const char* mmft_last_error(void);
+/* Arithmetic of the MFMA-bound contractions (dense layers, convolutions, fused level MLPs), process-wide:
+ *   MMFT_MATH_F32  (default) exact fp32: v_mfma_f32_16x16x4_f32, a k-ordered fmaf chain - the 1e-4 parity mode;
+ *   MMFT_MATH_BF16 operands rounded to bf16 (round to nearest even) on their way into LDS / registers, products
+ *                  summed in fp32 on v_mfma_f32_16x16x32_bf16 (16x the fp32 matrix rate) - the throughput mode
+ *                  BASELINE.json configs[1] names.  Tensors in HBM stay fp32 in both modes; aggregation, BatchNorm,
+ *                  loss and Adam arithmetic is fp32 in both modes. */
+#define MMFT_MATH_F32 0
+#define MMFT_MATH_BF16 1
+int mmft_set_math_mode(int mode);
+int mmft_get_math_mode(void);
 /* Launch profiling for bench.py's roofline line: while enabled, every instrumented kernel launch is
  * bracketed by HIP events on ITS launch stream; mmft_prof_report writes one line per kernel name
  * ("name\tlaunches\ttotal_ms\talgorithmic_flops\talgorithmic_bytes") and returns the size needed.
@@ -299,6 +309,17 @@ int mmft_adam_step_dev(float* p, const float* g, float* m, float* v, long long n
  * the host running ahead of the device.  state is two int32 words, zeroed by the caller before the first step. */
 int mmft_adam_step_counted(float* p, const float* g, float* m, float* v, long long n, int* state, float lr, float beta1,
                            float beta2, float eps, float weight_decay, float gscale, int device, void* stream);
+
+/* ---- stream / event plumbing for the data-parallel step (mmft.dist.GradReducer) ----
+ * An event that an event-record NODE inside a captured HIP graph records on every replay (external != 0 while the
+ * stream is capturing: hipEventRecordWithFlags + hipEventRecordExternal), so that a stream OUTSIDE the graph can wait
+ * for a point in the middle of the replayed backward pass - the moment a gradient bucket is complete - and start that
+ * bucket's all-reduce underneath the rest of it.  Outside a capture the record is an ordinary hipEventRecord. */
+int mmft_event_create(void** event);
+int mmft_event_destroy(void* event);
+int mmft_event_record(void* event, int external, int device, void* stream);
+int mmft_stream_wait_event(void* stream, void* event, int device);
+int mmft_stream_is_capturing(void* stream, int device);          /* 1 / 0 */
 
 /* ---- design preprocessing: the graph-side steps the reference runs on networkx in Python ---- */
 /* Longest-path levels from the primary inputs `pis` (src/verilog_parser_asap7.py:1452-1517, cal_topo_level: frontier

@@ -26,7 +26,7 @@ struct ConvDirectArgs {
   int flip;            // 1: input-gradient use - w is the FORWARD weight [CI][3][3][CO] of the layer, read flipped
 };
 
-template <int CI, int CO>
+template <int CI, int CO, bool BF>   // BF: operands rounded to bf16 at the MFMA (MMFT_MATH_BF16)
 __global__ void __launch_bounds__(256) conv3x3_direct_kernel(ConvDirectArgs a) {
   constexpr int K = 9 * CI, WS = K + 4;          // (K + 4) / 4 is odd: conflict-free b128 fragment reads
   constexpr int NS = 4, CC = CI / 16, CS = CO / 16, STAGES = 3 * CC;
@@ -93,11 +93,18 @@ __global__ void __launch_bounds__(256) conv3x3_direct_kernel(ConvDirectArgs a) {
 #pragma unroll
         for (int cs = 0; cs < CS; ++cs) {
           f32x4 wf = *reinterpret_cast<const f32x4*>(wl + (cs * 16 + r) * WS + ((ky * 3 + kx) * CI + cc * 16) + 4 * q);
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
+          if constexpr (BF) {
+            const s16x4 wp = pack_bf16x4(wf);
 #pragma unroll
             for (int sub = 0; sub < NS; ++sub)
-              acc[sub][cs] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xf[buf][kx][sub][s], acc[sub][cs], 0, 0, 0);
+              acc[sub][cs] = mfma_bf16_k16(wp, pack_bf16x4(xf[buf][kx][sub]), acc[sub][cs]);
+          } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int sub = 0; sub < NS; ++sub)
+                acc[sub][cs] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xf[buf][kx][sub][s], acc[sub][cs], 0, 0, 0);
+          }
         }
     };
     auto run = [&](auto self, auto stc) -> void {
@@ -154,8 +161,12 @@ inline void conv_direct_launch_t(const ConvDirectArgs& a, hipStream_t st) {
   if (wgs > cap) wgs = cap;
   const double flops = 2.0 * a.N * a.H * a.W * CO * 9.0 * CI;
   const double bytes = 4.0 * a.N * a.H * a.W * (CI + CO) + 4.0 * CO * 9 * CI;
-  MMFT_LAUNCH_LDS("conv3x3_direct_kernel", flops, bytes, (conv3x3_direct_kernel<CI, CO>), dim3((unsigned)wgs), dim3(256), lds,
-                  st, a);
+  if (math_mode() == MMFT_MATH_BF16)
+    MMFT_LAUNCH_LDS("conv3x3_direct_kernel<bf16>", flops, bytes, (conv3x3_direct_kernel<CI, CO, true>), dim3((unsigned)wgs),
+                    dim3(256), lds, st, a);
+  else
+    MMFT_LAUNCH_LDS("conv3x3_direct_kernel", flops, bytes, (conv3x3_direct_kernel<CI, CO, false>), dim3((unsigned)wgs),
+                    dim3(256), lds, st, a);
 }
 
 inline int conv_direct_launch(const float* x, const float* w, const float* bias, float* y, int Nimg, int H, int W, int Ci,

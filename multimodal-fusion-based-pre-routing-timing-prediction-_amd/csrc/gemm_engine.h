@@ -40,6 +40,39 @@ namespace mmft {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// One 16-deep k block of a 16x16 output tile from operands held as fp32 fragments "4 consecutive k per lane quarter"
+// (the fragment layout of every hand-scheduled kernel of this library):
+//   BF = false: four v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fmaf chain);
+//   BF = true : the fragments are rounded to bf16 (v_cvt_pk_bf16_f32) and multiplied by ONE v_mfma_f32_16x16x16_bf16
+//               (lane quarter q supplies k = 4q..4q+3 on both operands - the same k placement), fp32 accumulate.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x4 pack_bf16x4(float a, float b, float c, float d) {
+  f32x2_t lo = {a, b}, hi = {c, d};
+  bf16x2_t l = __builtin_convertvector(lo, bf16x2_t), h = __builtin_convertvector(hi, bf16x2_t);
+  unsigned ul = __builtin_bit_cast(unsigned, l), uh = __builtin_bit_cast(unsigned, h);
+  s16x4 r;
+  r[0] = (short)(ul & 0xffff); r[1] = (short)(ul >> 16); r[2] = (short)(uh & 0xffff); r[3] = (short)(uh >> 16);
+  return r;
+}
+__device__ __forceinline__ s16x4 pack_bf16x4(f32x4 v) { return pack_bf16x4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ f32x4 mfma_bf16_k16(s16x4 a, s16x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+template <bool BF>
+__device__ __forceinline__ f32x4 mma_k16(f32x4 a, f32x4 b, f32x4 c) {
+  if constexpr (BF) {
+    return mfma_bf16_k16(pack_bf16x4(a), pack_bf16x4(b), c);
+  } else {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+    return c;
+  }
+}
+
 template <int BM_, int BN_, int BK_, int WM_, int WN_>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
@@ -621,6 +654,13 @@ inline double operand_bytes(const L& l, double rows, double depth) {
   else return 4.0 * rows * depth;
 }
 
+// math mode of the MFMA-bound contractions (mmft_set_math_mode): 0 = exact fp32 MFMA, 1 = bf16 operands / fp32 sums
+int math_mode();
+template <class CFG, class XL, class WL>
+__global__ void gemm_bf16_kernel(XL xl, WL wl, Epi epi, int M, int N, int K, int ksplit);
+template <class CFG, class XL, class WL>
+inline const char* gemm_bf16_kernel_name();
+
 template <class CFG, class XL, class WL>
 inline void launch_cfg(const XL& xl, const WL& wl, const Epi& epi, int M, int N, int K, int splits, hipStream_t st) {
   int ksplit = K;
@@ -635,6 +675,13 @@ inline void launch_cfg(const XL& xl, const WL& wl, const Epi& epi, int M, int N,
   dim3 grid((unsigned)((wgs + 7) / 8 * 8));                                  // 1-D, padded: see the XCD-aware tile order
   // algorithmic work of this launch: 2*M*N*K flops; bytes = the three matrices touched once
   const double alg_bytes = operand_bytes(xl, M, K) + operand_bytes(wl, N, K) + 4.0 * (double)M * N;
+  if (math_mode() == 1) {
+    // the bf16 MFMA consumes 32 k per instruction: the 16-deep tiles run with a 32-deep K step (same slab geometry,
+    // ksplit is a multiple of 16 and a K range that is not a multiple of BK ends in a zero-filled step)
+    using C2 = TileCfg<CFG::BM, CFG::BN, (CFG::BK < 32 ? 32 : CFG::BK), CFG::WM, CFG::WN>;
+    MMFT_LAUNCH((gemm_bf16_kernel_name<C2, XL, WL>()), 2.0 * M * N * K, alg_bytes, (gemm_bf16_kernel<C2, XL, WL>), grid, dim3(256), st, xl, wl, epi, M, N, K, ksplit);
+    return;
+  }
   MMFT_LAUNCH((gemm_kernel_name<CFG, XL, WL>()), 2.0 * M * N * K, alg_bytes, (gemm_f32_kernel<CFG, XL, WL>), grid, dim3(256), st, xl, wl, epi, M, N, K, ksplit);
 }
 
@@ -761,3 +808,4 @@ inline int launch_gemm(const XL& xl, const WL& wl, const Epi& epi, int M, int N,
 int launch_slab_reduce(const float* slabs, int splits, long long elems, float* out, int accumulate, hipStream_t st);
 
 }  // namespace mmft
+#include "gemm_bf16.h"

@@ -14,6 +14,10 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---------------------------------------------------------------- math mode (process-wide; backward runs on another thread)
+static int g_math_mode = 0;
+int math_mode() { return __atomic_load_n(&g_math_mode, __ATOMIC_RELAXED); }
+
 // ---------------------------------------------------------------- launch profiling
 }  // namespace mmft
 #include <mutex>
@@ -190,7 +194,15 @@ using namespace mmft;
 
 extern "C" {
 
-int mmft_version(void) { return 100; }
+int mmft_version(void) { return 200; }
+
+int mmft_set_math_mode(int mode) {
+  MMFT_REQUIRE(mode == MMFT_MATH_F32 || mode == MMFT_MATH_BF16, "set_math_mode: unknown mode %d", mode);
+  __atomic_store_n(&mmft::g_math_mode, mode, __ATOMIC_RELAXED);
+  return MMFT_OK;
+}
+
+int mmft_get_math_mode(void) { return mmft::math_mode(); }
 
 int mmft_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(mmft::g_prof_mu);

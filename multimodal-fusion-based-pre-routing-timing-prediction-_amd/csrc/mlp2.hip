@@ -16,7 +16,8 @@
 
 namespace mmft {
 
-template <bool KM, int NW>      // NW waves per workgroup: each owns 256 / NW hidden columns and 128 / NW output columns
+// BF: operands rounded to bf16 at the MFMA (v_mfma_f32_16x16x16_bf16, fp32 accumulate) - MMFT_MATH_BF16
+template <bool KM, int NW, bool BF>   // NW waves per workgroup: each owns 256 / NW hidden columns and 128 / NW output columns
 __global__ void __launch_bounds__(NW * 64, 1) mlp2_rows_kernel(Mlp2Args a) {
   constexpr int NT = NW * 64, HC = (M2_HD / 16) / NW, OC = (M2_D2 / 16) / NW;
   constexpr int XS = M2_K1 + 8;                       // 136: x1 tile, whole K resident
@@ -60,7 +61,7 @@ __global__ void __launch_bounds__(NW * 64, 1) mlp2_rows_kernel(Mlp2Args a) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < HC; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  Phase1<KM, 0, M2_K1 / M2_BK, false, NW>::run(p1, xs, wb, WSZ, tid, lane, wave, acc1);
+  Phase1<KM, 0, M2_K1 / M2_BK, false, NW, BF>::run(p1, xs, wb, WSZ, tid, lane, wave, acc1);
 
   // ---- epilogue 1: bias + ReLU, or ReLU mask from the saved forward hidden activations -> LDS (+ HBM)
 #pragma unroll
@@ -95,7 +96,7 @@ __global__ void __launch_bounds__(NW * 64, 1) mlp2_rows_kernel(Mlp2Args a) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < OC; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  Phase2<KM, 0, M2_HD / M2_BK, false, NW>::run(p2, hs, wb, WSZ, tid, lane, wave, acc2);
+  Phase2<KM, 0, M2_HD / M2_BK, false, NW, BF>::run(p2, hs, wb, WSZ, tid, lane, wave, acc2);
 
   // ---- epilogue 2: row scatter by node id
 #pragma unroll
@@ -150,12 +151,16 @@ extern "C" int mmft_mlp2_rows(const float* x1, long long ldx1, const int* rows, 
     const char* e = getenv("MMFT_MLP2_WAVES");         // tuning hook: 4 or 8 waves per workgroup
     nw = (e && atoi(e) == 4) ? 4 : 8;
   }
+  const bool bf = math_mode() == MMFT_MATH_BF16;
+#define MMFT_M2(KM, NWV, BFV, NAME) \
+  MMFT_LAUNCH(NAME, fl, by, (mlp2_rows_kernel<KM, NWV, BFV>), dim3(cdiv(n, M2_BM)), dim3(NWV * 64), st, a)
   if (weights_kmajor) {
-    if (nw == 8) MMFT_LAUNCH("mlp2_rows_kernel<KM>", fl, by, (mlp2_rows_kernel<true, 8>), dim3(cdiv(n, M2_BM)), dim3(512), st, a);
-    else MMFT_LAUNCH("mlp2_rows_kernel<KM>", fl, by, (mlp2_rows_kernel<true, 4>), dim3(cdiv(n, M2_BM)), dim3(256), st, a);
+    if (bf) { if (nw == 8) MMFT_M2(true, 8, true, "mlp2_rows_kernel<KM,bf16>"); else MMFT_M2(true, 4, true, "mlp2_rows_kernel<KM,bf16>"); }
+    else { if (nw == 8) MMFT_M2(true, 8, false, "mlp2_rows_kernel<KM>"); else MMFT_M2(true, 4, false, "mlp2_rows_kernel<KM>"); }
   } else {
-    if (nw == 8) MMFT_LAUNCH("mlp2_rows_kernel<MK>", fl, by, (mlp2_rows_kernel<false, 8>), dim3(cdiv(n, M2_BM)), dim3(512), st, a);
-    else MMFT_LAUNCH("mlp2_rows_kernel<MK>", fl, by, (mlp2_rows_kernel<false, 4>), dim3(cdiv(n, M2_BM)), dim3(256), st, a);
+    if (bf) { if (nw == 8) MMFT_M2(false, 8, true, "mlp2_rows_kernel<MK,bf16>"); else MMFT_M2(false, 4, true, "mlp2_rows_kernel<MK,bf16>"); }
+    else { if (nw == 8) MMFT_M2(false, 8, false, "mlp2_rows_kernel<MK>"); else MMFT_M2(false, 4, false, "mlp2_rows_kernel<MK>"); }
   }
+#undef MMFT_M2
   return check_launch("mlp2_rows");
 }

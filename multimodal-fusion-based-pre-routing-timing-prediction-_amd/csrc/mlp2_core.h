@@ -69,7 +69,7 @@ struct WPanel {
 
 // SINGLE = one weight tile buffer in LDS (two barriers per K step) instead of two (one barrier): the persistent
 // sweep kernel keeps its LDS footprint small so that the U-Net's kernels can share the CUs it occupies.
-template <bool KM, int KTI, int NK, bool SINGLE = false, int NW = 4>
+template <bool KM, int KTI, int NK, bool SINGLE = false, int NW = 4, bool BF = false>
 struct Phase1 {
   static constexpr int HC = (M2_HD / 16) / NW;       // hidden-column subtiles per wave
   template <class P>
@@ -88,19 +88,31 @@ struct Phase1 {
       for (int i = 0; i < 2; ++i) read_frag<false, XS>(xs, i * 16, KTI * (M2_BK / 16) + kb, lane, xf[i]);
 #pragma unroll
       for (int j = 0; j < HC; ++j) read_frag<KM, WS>(wt, wave * (HC * 16) + j * 16, kb, lane, wf[j]);
+      if constexpr (BF) {
+        s16x4 xp[2], wp[HC];
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int i = 0; i < 2; ++i) xp[i] = pack_bf16x4(xf[i][0], xf[i][1], xf[i][2], xf[i][3]);
+#pragma unroll
+        for (int j = 0; j < HC; ++j) wp[j] = pack_bf16x4(wf[j][0], wf[j][1], wf[j][2], wf[j][3]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < HC; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][s], xf[i][s], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < HC; ++j) acc[i][j] = mfma_bf16_k16(wp[j], xp[i], acc[i][j]);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < HC; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][s], xf[i][s], acc[i][j], 0, 0, 0);
+      }
     }
-    if constexpr (KTI + 1 < NK) Phase1<KM, KTI + 1, NK, SINGLE, NW>::run(pan, xs, wb, wsz, tid, lane, wave, acc);
+    if constexpr (KTI + 1 < NK) Phase1<KM, KTI + 1, NK, SINGLE, NW, BF>::run(pan, xs, wb, wsz, tid, lane, wave, acc);
   }
 };
 
-template <bool KM, int KTI, int NK, bool SINGLE = false, int NW = 4>
+template <bool KM, int KTI, int NK, bool SINGLE = false, int NW = 4, bool BF = false>
 struct Phase2 {
   static constexpr int OC = (M2_D2 / 16) / NW;       // output-column subtiles per wave
   template <class P>
@@ -119,15 +131,27 @@ struct Phase2 {
       for (int i = 0; i < 2; ++i) read_frag<false, HS>(hs, i * 16, KTI * (M2_BK / 16) + kb, lane, xf[i]);
 #pragma unroll
       for (int j = 0; j < OC; ++j) read_frag<KM, WS>(wt, wave * (OC * 16) + j * 16, kb, lane, wf[j]);
+      if constexpr (BF) {
+        s16x4 xp[2], wp[OC];
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int i = 0; i < 2; ++i) xp[i] = pack_bf16x4(xf[i][0], xf[i][1], xf[i][2], xf[i][3]);
+#pragma unroll
+        for (int j = 0; j < OC; ++j) wp[j] = pack_bf16x4(wf[j][0], wf[j][1], wf[j][2], wf[j][3]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < OC; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][s], xf[i][s], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < OC; ++j) acc[i][j] = mfma_bf16_k16(wp[j], xp[i], acc[i][j]);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < OC; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][s], xf[i][s], acc[i][j], 0, 0, 0);
+      }
     }
-    if constexpr (KTI + 1 < NK) Phase2<KM, KTI + 1, NK, SINGLE, NW>::run(pan, hs, wb, wsz, tid, lane, wave, acc);
+    if constexpr (KTI + 1 < NK) Phase2<KM, KTI + 1, NK, SINGLE, NW, BF>::run(pan, hs, wb, wsz, tid, lane, wave, acc);
   }
 };
 

@@ -42,7 +42,7 @@ struct MlpGradArgs {
   long long wstride, bstride;
 };
 
-template <int FT>   // input-feature subtiles of 16 (fin <= 16 * FT)
+template <int FT, bool BF>   // input-feature subtiles of 16 (fin <= 16 * FT); BF: bf16 operands at the MFMAs (MMFT_MATH_BF16)
 __global__ void __launch_bounds__(MG_WAVES * 64, 1) mlp_first_layer_grads_kernel(MlpGradArgs a) {
   constexpr int KB = MG_D2 / 16;           // 8 K chunks of 16 for MFMA #1
   extern __shared__ __attribute__((aligned(16))) float w2t[];      // [HD][D2 + 8]: W2^T, conflict-free b128 reads
@@ -133,14 +133,20 @@ __global__ void __launch_bounds__(MG_WAVES * 64, 1) mlp_first_layer_grads_kernel
           w[(kb + 1) & 1][j] = *reinterpret_cast<const f32x4*>(wl + (ncol0 + j * 16 + r) * MG_WS + (kb + 1) * 16 + 4 * q);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (BF) {
+        const s16x4 gp = pack_bf16x4(gc[kb]);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int j = 0; j < 4; ++j) acc1[j] = mfma_bf16_k16(gp, pack_bf16x4(w[kb & 1][j]), acc1[j]);
+      } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          // i axis = rows (A = G), j axis = hidden columns (B = W2^T): lane gets rows 4q..4q+3 of column lane&15
-          acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gc[kb][s], w[kb & 1][j][s], acc1[j], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            // i axis = rows (A = G), j axis = hidden columns (B = W2^T): lane gets rows 4q..4q+3 of column lane&15
+            acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gc[kb][s], w[kb & 1][j][s], acc1[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      }
     }
 
     // ---- ReLU mask, bias-gradient partials, MFMA #2 with the masked dH straight from the accumulators
@@ -153,13 +159,25 @@ __global__ void __launch_bounds__(MG_WAVES * 64, 1) mlp_first_layer_grads_kernel
         cs[j] += v;
       }
     }
+    if constexpr (BF) {
+      s16x4 dp[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+      for (int j = 0; j < 4; ++j) dp[j] = pack_bf16x4(acc1[j]);
 #pragma unroll
-      for (int f = 0; f < FT; ++f)
+      for (int f = 0; f < FT; ++f) {
+        const s16x4 xp = pack_bf16x4(xt[f][0], xt[f][1], xt[f][2], xt[f][3]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc2[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[f][s], acc1[j][s], acc2[f][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc2[f][j] = mfma_bf16_k16(xp, dp[j], acc2[f][j]);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc2[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[f][s], acc1[j][s], acc2[f][j], 0, 0, 0);
+    }
 
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // next G block: requested a whole block ago
 #pragma unroll
@@ -237,25 +255,31 @@ extern "C" int mmft_mlp2_first_layer_grads(const float* g, long long ldg, const 
   MlpGradArgs a{g, ldg, hid, ldh, x, ldx, rows, row0, n, fin, w2, ldw2, slab_w, slab_b, wslab, joined ? wslab : (long long)HD};
   const size_t lds = (size_t)MG_HD * MG_WS * 4;
   const int ft = (fin + 15) / 16;
-  static bool attr_done[4] = {false, false, false, false};
+  const bool bf = math_mode() == MMFT_MATH_BF16;
+  static bool attr_done[2][4] = {{false, false, false, false}, {false, false, false, false}};
   auto set_attr = [&](const void* k) {
-    if (!attr_done[ft]) {
+    if (!attr_done[bf][ft]) {
       (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_done[ft] = true;
+      attr_done[bf][ft] = true;
     }
   };
   const double fl = 2.0 * n * ((double)D2 * HD + (double)HD * ft * 16), by = 4.0 * n * ((double)D2 + HD + fin);
   const dim3 gr(grid), bl(MG_WAVES * 64);
-  if (ft == 1) {
-    set_attr((const void*)mlp_first_layer_grads_kernel<1>);
-    MMFT_LAUNCH_LDS("mlp_first_layer_grads_kernel", fl, by, mlp_first_layer_grads_kernel<1>, gr, bl, lds, st, a);
-  } else if (ft == 2) {
-    set_attr((const void*)mlp_first_layer_grads_kernel<2>);
-    MMFT_LAUNCH_LDS("mlp_first_layer_grads_kernel", fl, by, mlp_first_layer_grads_kernel<2>, gr, bl, lds, st, a);
+#define MMFT_MG(FTV, BFV, NAME)                                                                       \
+  do {                                                                                                \
+    set_attr((const void*)mlp_first_layer_grads_kernel<FTV, BFV>);                                    \
+    MMFT_LAUNCH_LDS(NAME, fl, by, (mlp_first_layer_grads_kernel<FTV, BFV>), gr, bl, lds, st, a);      \
+  } while (0)
+  if (bf) {
+    if (ft == 1) MMFT_MG(1, true, "mlp_first_layer_grads_kernel<bf16>");
+    else if (ft == 2) MMFT_MG(2, true, "mlp_first_layer_grads_kernel<bf16>");
+    else MMFT_MG(3, true, "mlp_first_layer_grads_kernel<bf16>");
   } else {
-    set_attr((const void*)mlp_first_layer_grads_kernel<3>);
-    MMFT_LAUNCH_LDS("mlp_first_layer_grads_kernel", fl, by, mlp_first_layer_grads_kernel<3>, gr, bl, lds, st, a);
+    if (ft == 1) MMFT_MG(1, false, "mlp_first_layer_grads_kernel");
+    else if (ft == 2) MMFT_MG(2, false, "mlp_first_layer_grads_kernel");
+    else MMFT_MG(3, false, "mlp_first_layer_grads_kernel");
   }
+#undef MMFT_MG
   int rc = check_launch("mlp2_first_layer_grads");
   if (rc) return rc;
   if (joined) return launch_slab_reduce(slab_w, 2 * grid, wslab, dw1, accumulate, st);

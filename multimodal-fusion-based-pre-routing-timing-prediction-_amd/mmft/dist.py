@@ -44,8 +44,9 @@ class GradReducer:
 
     Collectives are issued in bucket order on every rank whatever order the buckets complete in (a bucket that
     completes early waits for its predecessors).  No collective is ever captured in a HIP graph: under
-    GraphedTrainStep the events are recorded by event-record nodes inside the graph (torch.cuda.Event(external=True))
-    and the communication stream waits for them after each replay; MIDGRAPH_EVENTS = False falls back to waiting for
+    GraphedTrainStep the events are recorded by event-record nodes inside the graph (mmft.lib.GraphEvent:
+    hipEventRecordWithFlags + hipEventRecordExternal through the C ABI) and the communication stream waits for them
+    after each replay; MIDGRAPH_EVENTS = False falls back to waiting for
     the whole replay.
     """
     MIDGRAPH_EVENTS = True
@@ -81,19 +82,20 @@ class GradReducer:
             return
         if self.capturing and not self.MIDGRAPH_EVENTS:
             return
+        from . import lib
         evs = []
         for s in self._streams():
             if self.capturing:
                 # only a stream that is part of the capture right now can take an event-record node; one that is not
                 # (the side stream before the reverse sweep forks it / after it has rejoined) has nothing pending
                 # that the main stream's event does not cover
-                with torch.cuda.stream(s):
-                    if not torch.cuda.is_current_stream_capturing():
-                        continue
-                ev = torch.cuda.Event(external=True)
+                if not lib.stream_is_capturing(s, self.device):
+                    continue
+                ev = lib.GraphEvent(self.device)        # recorded by an event-record node on every replay
+                ev.record(s, external=True)
             else:
                 ev = torch.cuda.Event()
-            ev.record(s)
+                ev.record(s)
             evs.append(ev)
         self.events[bucket.index], self.ready[bucket.index] = evs, True
         if not self.capturing:
@@ -112,7 +114,10 @@ class GradReducer:
                     self.comm.wait_stream(s)
             else:
                 for ev in evs:
-                    self.comm.wait_event(ev)
+                    if isinstance(ev, torch.cuda.Event):
+                        self.comm.wait_event(ev)
+                    else:
+                        ev.wait(self.comm)
             scale = allreduce_sum_(self.optim.flat_grad[lo:hi], self.world)
             self.optim.step_bucket(i, gscale=scale)
 

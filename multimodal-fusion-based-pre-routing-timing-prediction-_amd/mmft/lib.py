@@ -111,3 +111,65 @@ def workspace(device, nbytes):
         buf = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
         _workspace[key] = buf
     return buf
+
+
+class GraphEvent:
+    """A HIP event that can be recorded by an event-record node inside a captured graph (see mmft_event_record in
+    include/mmft.h); torch.cuda.Event(external=True) is refused on ROCm builds of PyTorch."""
+
+    def __init__(self, device):
+        self.device = torch.device(device).index or 0
+        h = ctypes.c_void_p()
+        call('mmft_event_create', ctypes.byref(h))
+        self.handle = h.value
+
+    def record(self, stream, external=True):
+        call('mmft_event_record', self.handle, int(external), self.device, stream.cuda_stream)
+
+    def wait(self, stream):
+        """Make `stream` wait for the most recent record of this event."""
+        call('mmft_stream_wait_event', stream.cuda_stream, self.handle, self.device)
+
+    def __del__(self):
+        try:
+            if self.handle and _lib is not None:
+                _lib.mmft_event_destroy(self.handle)
+        except Exception:                       # interpreter shutdown
+            pass
+
+
+def stream_is_capturing(stream, device):
+    return bool(query('mmft_stream_is_capturing', stream.cuda_stream, torch.device(device).index or 0))
+
+
+MATH_MODES = {'f32': 0, 'bf16': 1}
+
+
+def set_math_mode(mode):
+    """'f32' (default): exact fp32 MFMA everywhere - the 1e-4 parity mode.  'bf16': the MFMA-bound contractions (dense
+    layers, convolutions, fused level MLPs) round their operands to bf16 and accumulate in fp32 (mmft_set_math_mode in
+    include/mmft.h).  Process-wide: the backward pass runs on another thread."""
+    if mode not in MATH_MODES:
+        raise ValueError(f'unknown math mode {mode!r} (expected one of {sorted(MATH_MODES)})')
+    call('mmft_set_math_mode', MATH_MODES[mode])
+
+
+def get_math_mode():
+    code = query('mmft_get_math_mode')
+    return next(k for k, v in MATH_MODES.items() if v == code)
+
+
+class math_mode:
+    """with lib.math_mode('bf16'): ...  (restores the previous mode)."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = get_math_mode()
+        set_math_mode(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_math_mode(self.prev)
+        return False

@@ -1,0 +1,194 @@
+"""MMFT_MATH_BF16 (BASELINE.json configs[1]: "bf16"): the MFMA-bound contractions round their operands to bf16 and
+accumulate in fp32; tensors in HBM stay fp32.
+
+Two kinds of checks, both against fp64:
+  * EXACTNESS of the kernels: with operands that are already bf16-representable the rounding is the identity, so a
+    single contraction must agree with fp64 to fp32-accumulation accuracy (2e-6 of the result's scale) - this pins
+    the bf16 MFMA fragment layouts, the in-register transposes and the staging of every operand loader;
+  * TOLERANCE on arbitrary fp32 data: bf16 keeps 8 significant bits (relative rounding error <= 2^-9 per operand), the
+    stated tolerance is 2e-2 of the result's scale for one contraction and for the fused two-layer kernels, and
+    5e-2 on the predictions of a whole config-A train step (64 chained levels) with gradient directions within
+    cos >= 0.98 of the fp64 oracle's.
+fp32 stays the 1e-4 parity mode (every other GPU test)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from mmft import lib, ops
+from oracle import restatement as R
+
+pytestmark = pytest.mark.gpu
+EXACT, TOL = 2e-6, 2e-2
+
+
+def bf(t):
+    return t.bfloat16().float()
+
+
+def rnd(*shape, seed=0, representable=False):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randn(*shape, generator=g)
+    return bf(t) if representable else t
+
+
+@pytest.fixture(autouse=True)
+def _bf16_mode():
+    with lib.math_mode('bf16'):
+        yield
+    assert lib.get_math_mode() == 'f32'
+
+
+@pytest.mark.parametrize('M,N,K', [(9, 7, 5), (300, 256, 36), (1000, 128, 256), (257, 576, 288), (4099, 32, 1), (64, 128, 2)])
+@pytest.mark.parametrize('representable', [True, False])
+def test_linear_fwd_dgrad(dev, M, N, K, representable):
+    x, w, b = rnd(M, K, seed=1, representable=representable), rnd(N, K, seed=2, representable=representable), rnd(N, seed=3)
+    tol = EXACT if representable else TOL
+    y = ops.linear_fwd(x.to(dev), w.to(dev), b.to(dev), act=ops.ACT_RELU)
+    ref = torch.relu(x.double() @ w.double().T + b.double())
+    assert rel_err(y, ref) < tol
+    g = rnd(M, N, seed=4, representable=representable)
+    dx = ops.linear_dgrad(g.to(dev), w.to(dev))
+    assert rel_err(dx, g.double() @ w.double()) < tol
+
+
+@pytest.mark.parametrize('rows,out,inn', [(5, 7, 3), (1000, 128, 256), (40000, 256, 36), (30000, 128, 2), (70000, 256, 128)])
+@pytest.mark.parametrize('representable', [True, False])
+def test_linear_wgrad_with_bias(dev, rows, out, inn, representable):
+    g, x = rnd(rows, out, seed=5, representable=representable), rnd(rows, inn, seed=6, representable=representable)
+    dw, db = ops.linear_wgrad(g.to(dev), x.to(dev), with_bias=True)
+    scale = EXACT * 8 if representable else TOL           # up to 70 000-term fp32 sums
+    assert rel_err(dw, g.double().T @ x.double()) < scale
+    # the bias gradient is taken from the fp32 staging registers: exact in both cases
+    assert rel_err(db, g.double().sum(0)) < 1e-5
+    # indexed rows (gather on the reduction axis)
+    idx = torch.randperm(rows)[:max(rows // 2, 1)].to(torch.int32)
+    dw2 = ops.linear_wgrad(g.to(dev), x.to(dev), gidx=idx.to(dev), xidx=idx.to(dev))
+    assert rel_err(dw2, g[idx.long()].double().T @ x[idx.long()].double()) < scale
+
+
+@pytest.mark.parametrize('N,H,W,Ci,Co,k', [(2, 9, 64, 16, 16, 3), (1, 64, 128, 16, 32, 3), (2, 33, 64, 32, 32, 3),
+                                           (2, 16, 16, 64, 128, 3), (1, 12, 20, 3, 16, 3), (1, 24, 24, 2, 32, 9),
+                                           (2, 8, 8, 16, 1, 1)])
+@pytest.mark.parametrize('representable', [True, False])
+def test_conv_forward_dgrad_wgrad(dev, N, H, W, Ci, Co, k, representable):
+    x = rnd(N, Ci, H, W, seed=7, representable=representable)
+    w = rnd(Co, Ci, k, k, seed=8, representable=representable) * (0.25 if not representable else 1.0)
+    if representable:
+        w = bf(w)
+    gy = rnd(N, Co, H, W, seed=9, representable=representable)
+    pad = k // 2
+    tol = EXACT * 4 if representable else TOL
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xd, wd, None, padding=pad)
+    ref.backward(gy.double())
+    xn, gn = ops.to_nhwc(x.to(dev)), ops.to_nhwc(gy.to(dev))
+    wg = w.to(dev).contiguous(memory_format=torch.channels_last)
+    y = ops.conv2d_fwd(xn, wg, None, pad)
+    assert rel_err(y, ref) < tol
+    dx = ops.conv2d_dgrad(gn, wg, pad)
+    assert rel_err(dx, xd.grad) < tol
+    dw = ops.conv2d_wgrad(xn, gn, k, k, pad).permute(0, 3, 1, 2)
+    assert rel_err(dw, wd.grad) < tol
+
+
+@pytest.mark.parametrize('n', [1, 31, 1000, 8064])
+def test_mlp2_rows_fused(dev, n):
+    """Fused Linear-ReLU-Linear of the level chain: the hidden tile is rounded to bf16 between the layers."""
+    N = n + 50
+    x1, w1, b1 = rnd(N, 128, seed=10), rnd(256, 128, seed=11) * 0.1, rnd(256, seed=12) * 0.1
+    w2, b2 = rnd(128, 256, seed=13) * 0.1, rnd(128, seed=14) * 0.1
+    rows = torch.randperm(N)[:n].to(torch.int32)
+    old = rnd(N, 128, seed=15)
+    out, hid = old.clone().to(dev), torch.zeros(N, 256, device=dev)
+    ops.mlp2_rows(x1.to(dev), rows.to(dev), w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), out, hid_out=hid, add_act=True,
+                  relu_out=True)
+    r = rows.long()
+    h = torch.relu(x1[r].double() @ w1.double().T + b1.double())
+    ref = old.double().clone()
+    ref[r] = torch.relu(old[r].double() + h @ w2.double().T + b2.double())
+    assert rel_err(hid[r.to(dev)], h) < TOL
+    assert rel_err(out, ref) < TOL
+    # reverse form: weights read transposed, ReLU mask from the saved hidden activations
+    g = rnd(N, 128, seed=16)
+    da = torch.zeros(N, 128, device=dev)
+    ops.mlp2_rows(g.to(dev), rows.to(dev), w2.to(dev), None, w1.to(dev), None, da, kmajor=True, mask=hid)
+    dref = ((g[r].double() @ w2.double()) * (h > 0)) @ w1.double()
+    assert rel_err(da[r.to(dev)], dref) < TOL
+
+
+@pytest.mark.parametrize('fin,n', [(36, 5000), (2, 4099), (48, 37)])
+def test_first_layer_grads_fused(dev, fin, n):
+    g, hid, x, w2 = rnd(n, 128, seed=17), rnd(n, 256, seed=18), rnd(n, fin, seed=19), rnd(128, 256, seed=20) * 0.1
+    dw1, db1 = ops.mlp2_first_layer_grads(g.to(dev), hid.to(dev), x.to(dev), None, w2.to(dev))
+    dh = (g.double() @ w2.double()) * (hid > 0)
+    assert rel_err(dw1, dh.T @ x.double()) < TOL
+    assert rel_err(db1, dh.sum(0)) < TOL
+
+
+def _cos(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+def test_config_a_step_vs_oracle_bf16(dev):
+    """One full config-A train step (U-Net, 32-level sweep, fusion head, MSE, backward) in bf16 mode against the fp64
+    oracle: predictions within 5e-2 of their scale, loss within 10 %, every parameter gradient within cos >= 0.98."""
+    from mmft.synth import config_design
+    from mmft.train import build_models, TrainStep
+    from mmft.fusion import mse_loss
+    d = config_design('A')
+    pmodel, cnn = build_models(map_size=d.map_size, device=dev, seed=9294)
+    pm_state = {k: v.detach().cpu().clone() for k, v in pmodel.state_dict().items()}
+    pc_state = {k: v.detach().cpu().clone() for k, v in cnn.state_dict().items()}
+    oracle = R.OracleTrainer(pm_state, pc_state, dtype=torch.float64)
+    path_ids = np.random.default_rng(1).permutation(d.num_paths)[:100].tolist()
+    hats_o, tl_o, _ = oracle.forward(d, R.design_csr(d), path_ids)
+    arr_o = torch.from_numpy(d.arrival_time).double()[torch.tensor(tl_o)].squeeze(-1)
+    loss_o = torch.nn.functional.mse_loss(hats_o, arr_o)
+    loss_o.backward()
+    ts = TrainStep(pmodel, cnn, [d], dev)
+    hats, ends_d, ends_h = ts.forward([path_ids])
+    loss = mse_loss(hats, ts.batch.arrival[ends_d.long()].squeeze(-1))
+    ts.optim.zero_grad()
+    loss.backward()
+    assert ends_h.tolist() == tl_o
+    assert rel_err(hats, hats_o) < 5e-2
+    assert abs(float(loss) - float(loss_o)) < 0.1 * float(loss_o)
+    worst = 1.0
+    for k, prm in list(pmodel.named_parameters()) + list(cnn.named_parameters()):
+        o = oracle.pm.get(k, oracle.pc.get(k))
+        if o is None or o.grad is None or float(o.grad.abs().max()) == 0.0:
+            continue
+        c = _cos(prm.grad, o.grad)
+        worst = min(worst, c)
+        assert c > 0.98, (k, c)
+    # and the mode really changes the arithmetic: fp32 mode is >100x closer
+    with lib.math_mode('f32'):
+        hats32, _, _ = ts.forward([path_ids])
+    assert rel_err(hats32, hats_o) < 1e-4 < rel_err(hats, hats_o)
+
+
+def test_training_in_bf16_tracks_fp32(dev):
+    """40 optimizer steps from the same initialisation on the same batches: the bf16 run's loss curve stays within 15 % of
+    the fp32 run's and the held-out endpoint-slack MAE within 20 % (the drift bench.py reports)."""
+    from mmft.synth import synth_design
+    from mmft.train import build_models, TrainStep
+    from mmft.evaluate import validate
+    designs = [synth_design(N=4096, L=16, tile=64, seed=500 + i, end_frac=0.25) for i in range(2)]
+    held = synth_design(N=4096, L=16, tile=64, seed=777, end_frac=0.25)
+    rng = np.random.default_rng(4)
+    batches = [[rng.permutation(d.num_paths)[:64].tolist() for d in designs] for _ in range(40)]
+    res = {}
+    for mode in ('f32', 'bf16'):
+        with lib.math_mode(mode):
+            pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=3)
+            ts = TrainStep(pmodel, cnn, designs, dev)
+            losses = [float(ts.step(ids)[0]) for ids in batches]
+            ev = TrainStep(pmodel, cnn, [held], dev, overlap=False, with_optimizer=False)
+            res[mode] = (losses, validate(ev)['endpoint_slack_mae'])
+    l32, l16 = np.array(res['f32'][0]), np.array(res['bf16'][0])
+    assert l16[-1] < 0.5 * l16[0]                                         # it trains
+    assert np.abs(l16[-10:].mean() - l32[-10:].mean()) < 0.15 * l32[-10:].mean() + 1e-4
+    assert abs(res['bf16'][1] - res['f32'][1]) < 0.2 * res['f32'][1] + 1e-3

@@ -261,14 +261,16 @@ def test_bench_self_launches_its_ranks(dev):
 
 def test_in_graph_event_orders_the_communication_stream(dev):
     """What GradReducer relies on under graph replay: an event recorded by an event-record node INSIDE a captured graph
-    (torch.cuda.Event(external=True)) orders a wait issued on another stream after the replay - and that stream runs
-    while the rest of the graph is still executing."""
+    (mmft.lib.GraphEvent: hipEventRecordWithFlags + hipEventRecordExternal; torch.cuda.Event(external=True) is refused
+    on ROCm) orders a wait issued on another stream after the replay - and that stream runs while the rest of the graph
+    is still executing."""
+    from mmft import lib
     n = 1 << 22
     x = torch.zeros(n, device=dev)
     big = torch.randn(4096, 4096, device=dev)
     sink = torch.empty_like(big)
     counter = torch.zeros(1, device=dev)
-    ev = torch.cuda.Event(external=True)
+    ev = lib.GraphEvent(dev)
     side = torch.cuda.Stream(device=dev)
     warm = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(warm):
@@ -278,7 +280,7 @@ def test_in_graph_event_orders_the_communication_stream(dev):
     with torch.cuda.graph(g):
         counter += 1
         x.copy_(counter.expand(n))                  # "gradient bucket complete"
-        ev.record(torch.cuda.current_stream(dev))
+        ev.record(torch.cuda.current_stream(dev), external=True)
         for _ in range(6):                          # the rest of the backward: a few ms of work
             torch.mm(big, big, out=sink)
     ys = torch.zeros(20, n // 1024, device=dev)
@@ -286,7 +288,7 @@ def test_in_graph_event_orders_the_communication_stream(dev):
     for i in range(20):
         g.replay()
         with torch.cuda.stream(side):
-            side.wait_event(ev)
+            ev.wait(side)
             ys[i].copy_(x[::1024])
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(side)
