@@ -310,17 +310,6 @@ int mmft_adam_step_dev(float* p, const float* g, float* m, float* v, long long n
 int mmft_adam_step_counted(float* p, const float* g, float* m, float* v, long long n, int* state, float lr, float beta1,
                            float beta2, float eps, float weight_decay, float gscale, int device, void* stream);
 
-/* ---- stream / event plumbing for the data-parallel step (mmft.dist.GradReducer) ----
- * An event that an event-record NODE inside a captured HIP graph records on every replay (external != 0 while the
- * stream is capturing: hipEventRecordWithFlags + hipEventRecordExternal), so that a stream OUTSIDE the graph can wait
- * for a point in the middle of the replayed backward pass - the moment a gradient bucket is complete - and start that
- * bucket's all-reduce underneath the rest of it.  Outside a capture the record is an ordinary hipEventRecord. */
-int mmft_event_create(void** event);
-int mmft_event_destroy(void* event);
-int mmft_event_record(void* event, int external, int device, void* stream);
-int mmft_stream_wait_event(void* stream, void* event, int device);
-int mmft_stream_is_capturing(void* stream, int device);          /* 1 / 0 */
-
 /* ---- design preprocessing: the graph-side steps the reference runs on networkx in Python ---- */
 /* Longest-path levels from the primary inputs `pis` (src/verilog_parser_asap7.py:1452-1517, cal_topo_level: frontier
  * expansion + reverse de-duplication = every node keeps the LAST level it appears in).  Up to two out-edge CSRs

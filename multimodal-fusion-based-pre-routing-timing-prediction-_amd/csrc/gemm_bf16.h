@@ -68,7 +68,9 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(XL xl, WL wl, Epi epi, i
   for (int i = 0; i < XN; ++i) {
     int g = tid + i * 256;
     if (XL::KMAJOR) {
-      int k8 = g / (BM / 4), m4 = g % (BM / 4);
+      // k8 fastest: the BK/8 lanes of one m4 group write one contiguous piece of each LDS row (conflict-free) and
+      // every global load instruction still covers whole 128-byte lines
+      int m4 = g / (BK / 8), k8 = g % (BK / 8);
       xc[i] = xl.ctx(m0 + m4 * 4);
       xk[i] = k8 * 8;
       xo[i] = (m4 * 4) * SB + k8 * 8;
@@ -83,7 +85,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(XL xl, WL wl, Epi epi, i
   for (int i = 0; i < WNL; ++i) {
     int g = tid + i * 256;
     if (WL::KMAJOR) {
-      int k8 = g / (BN / 4), n4 = g % (BN / 4);
+      int n4 = g / (BK / 8), k8 = g % (BK / 8);
       wc[i] = wl.ctx(n0 + n4 * 4);
       wk[i] = k8 * 8;
       wo[i] = (n4 * 4) * SB + k8 * 8;
@@ -111,26 +113,40 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(XL xl, WL wl, Epi epi, i
   const bool x_in = has_fast<XL>::value && fast_interior(xl, m0, BM);
   const bool w_in = has_fast<WL>::value && fast_interior(wl, n0, BN);
   auto gload = [&](int k0) {
+    // MK: two loads of 4 consecutive k; KM: eight loads, one per k row.  The interior / edge decision is made ONCE per
+    // tile and operand (block-uniform): a per-load choice makes the compiler branch around every load and wait for
+    // each one in turn.
     const bool whole = k0 + BK <= kend;
-    // MK: two loads of 4 consecutive k; KM: eight loads, one per k row
+    if (x_in && whole) {
 #pragma unroll
-    for (int i = 0; i < XN; ++i)
-      if (XG % 256 == 0 || tid + i * 256 < XG) {
+      for (int i = 0; i < XN; ++i)
+        if (XG % 256 == 0 || tid + i * 256 < XG) {
 #pragma unroll
-        for (int v = 0; v < XV; ++v) {
-          const int k = k0 + xk[i] + (XL::KMAJOR ? v : 4 * v);
-          xr[i][v] = (x_in && whole) ? fast_load(xl, xc[i], k, kend) : xl.load(xc[i], k, kend);
+          for (int v = 0; v < XV; ++v) xr[i][v] = fast_load(xl, xc[i], k0 + xk[i] + (XL::KMAJOR ? v : 4 * v), kend);
         }
-      }
+    } else {
 #pragma unroll
-    for (int i = 0; i < WNL; ++i)
-      if (WG % 256 == 0 || tid + i * 256 < WG) {
+      for (int i = 0; i < XN; ++i)
+        if (XG % 256 == 0 || tid + i * 256 < XG) {
 #pragma unroll
-        for (int v = 0; v < WV; ++v) {
-          const int k = k0 + wk[i] + (WL::KMAJOR ? v : 4 * v);
-          wr[i][v] = (w_in && whole) ? fast_load(wl, wc[i], k, kend) : wl.load(wc[i], k, kend);
+          for (int v = 0; v < XV; ++v) xr[i][v] = xl.load(xc[i], k0 + xk[i] + (XL::KMAJOR ? v : 4 * v), kend);
         }
-      }
+    }
+    if (w_in && whole) {
+#pragma unroll
+      for (int i = 0; i < WNL; ++i)
+        if (WG % 256 == 0 || tid + i * 256 < WG) {
+#pragma unroll
+          for (int v = 0; v < WV; ++v) wr[i][v] = fast_load(wl, wc[i], k0 + wk[i] + (WL::KMAJOR ? v : 4 * v), kend);
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < WNL; ++i)
+        if (WG % 256 == 0 || tid + i * 256 < WG) {
+#pragma unroll
+          for (int v = 0; v < WV; ++v) wr[i][v] = wl.load(wc[i], k0 + wk[i] + (WL::KMAJOR ? v : 4 * v), kend);
+        }
+    }
   };
   auto put = [&](unsigned short* tile, int off, const f32x4* r, bool kmajor) {
     if (!kmajor) {
@@ -211,7 +227,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(XL xl, WL wl, Epi epi, i
     for (int i = 0; i < XN; ++i) {
       int g = tid + i * 256;
       if (XG % 256 == 0 || g < XG) {
-        int k8 = g / (BM / 4), m4 = g % (BM / 4);
+        int m4 = g / (BK / 8), k8 = g % (BK / 8);
         *reinterpret_cast<f32x4*>(red + k8 * BM + m4 * 4) = cs[i];
       }
     }

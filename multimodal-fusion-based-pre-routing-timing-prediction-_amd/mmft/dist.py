@@ -43,13 +43,13 @@ class GradReducer:
     reverse netlist sweep; the GNN + CNN bucket follows at the end.
 
     Collectives are issued in bucket order on every rank whatever order the buckets complete in (a bucket that
-    completes early waits for its predecessors).  No collective is ever captured in a HIP graph: under
-    GraphedTrainStep the events are recorded by event-record nodes inside the graph (mmft.lib.GraphEvent:
-    hipEventRecordWithFlags + hipEventRecordExternal through the C ABI) and the communication stream waits for them
-    after each replay; MIDGRAPH_EVENTS = False falls back to waiting for
-    the whole replay.
+    completes early waits for its predecessors).  No collective is ever captured in a HIP graph.  Under
+    GraphedTrainStep the forward + backward replay is ONE graph launch, and a point in the middle of it cannot be
+    signalled to a stream outside it on this stack: event-record nodes (hipEventRecordWithFlags +
+    hipEventRecordExternal) are refused by the HIP runtime PyTorch-ROCm 2.10 loads ("invalid argument"; torch itself
+    raises "External events are disallowed in rocm").  The replayed step therefore reduces every bucket behind the
+    whole replay, on the communication stream; the mid-backward overlap is what the eager step does.
     """
-    MIDGRAPH_EVENTS = True
 
     def __init__(self, optim, world_size, device, side_stream=None):
         from . import gradsink
@@ -62,14 +62,11 @@ class GradReducer:
             b = gradsink.Bucket(optim.bucket_ranges[i][0], params, self._on_complete)
             b.index = i
             self.buckets.append(b)
-        self.capturing = False
         self.main = None
         self.ready, self.events, self.issued = [], [], 0
-        self.graph_events = None            # per bucket: events recorded inside the captured graph (or None)
 
-    def begin(self, capturing=False):
-        """Call right before loss.backward() (after zero_grad)."""
-        self.capturing = capturing
+    def begin(self):
+        """Call right before loss.backward() of an EAGER step (after zero_grad)."""
         self.main = torch.cuda.current_stream(self.device)
         nb = len(self.buckets)
         self.ready, self.events, self.issued = [False] * nb, [None] * nb, 0
@@ -78,30 +75,14 @@ class GradReducer:
         return [self.main] + ([self.side] if self.side is not None else [])
 
     def _on_complete(self, bucket):
-        if self.main is None:
+        if self.main is None:                   # not inside an eager step (capture, evaluation, plain backward)
             return
-        if self.capturing and not self.MIDGRAPH_EVENTS:
-            return
-        from . import lib
         evs = []
         for s in self._streams():
-            if self.capturing:
-                # only a stream that is part of the capture right now can take an event-record node; one that is not
-                # (the side stream before the reverse sweep forks it / after it has rejoined) has nothing pending
-                # that the main stream's event does not cover
-                if not lib.stream_is_capturing(s, self.device):
-                    continue
-                ev = lib.GraphEvent(self.device)        # recorded by an event-record node on every replay
-                ev.record(s, external=True)
-            else:
-                ev = torch.cuda.Event()
-                ev.record(s)
+            ev = torch.cuda.Event()
+            ev.record(s)
             evs.append(ev)
         self.events[bucket.index], self.ready[bucket.index] = evs, True
-        if not self.capturing:
-            self._issue_ready()
-
-    def _issue_ready(self):
         while self.issued < len(self.buckets) and self.ready[self.issued]:
             self._reduce(self.issued, self.events[self.issued])
             self.issued += 1
@@ -114,10 +95,7 @@ class GradReducer:
                     self.comm.wait_stream(s)
             else:
                 for ev in evs:
-                    if isinstance(ev, torch.cuda.Event):
-                        self.comm.wait_event(ev)
-                    else:
-                        ev.wait(self.comm)
+                    self.comm.wait_event(ev)
             scale = allreduce_sum_(self.optim.flat_grad[lo:hi], self.world)
             self.optim.step_bucket(i, gscale=scale)
 
@@ -131,18 +109,11 @@ class GradReducer:
         self.optim.step_count += 1
         self.main = None
 
-    def end_capture(self):
-        """After the capture of forward + backward: keep the in-graph events for the replays."""
-        self.graph_events = list(self.events)
-        self.capturing = False
-        self.main = None
-
     def after_replay(self):
-        """Issue every bucket's all-reduce + Adam behind a graph replay that was just enqueued on the current stream."""
-        self.main = torch.cuda.current_stream(self.device)
+        """Issue every bucket's all-reduce + Adam behind a graph replay that was just enqueued on the current stream
+        (a graph launched on `main` is complete when `main` is)."""
+        main = torch.cuda.current_stream(self.device)
         for i in range(len(self.buckets)):
-            # a graph launched on `main` is complete when `main` is: no need to look at the captured side stream
-            self._reduce(i, self.graph_events[i] if self.graph_events is not None else None, streams=[self.main])
-        self.main.wait_stream(self.comm)
+            self._reduce(i, None, streams=[main])
+        main.wait_stream(self.comm)
         self.optim.step_count += 1
-        self.main = None

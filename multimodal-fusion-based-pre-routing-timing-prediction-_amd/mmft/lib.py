@@ -113,35 +113,6 @@ def workspace(device, nbytes):
     return buf
 
 
-class GraphEvent:
-    """A HIP event that can be recorded by an event-record node inside a captured graph (see mmft_event_record in
-    include/mmft.h); torch.cuda.Event(external=True) is refused on ROCm builds of PyTorch."""
-
-    def __init__(self, device):
-        self.device = torch.device(device).index or 0
-        h = ctypes.c_void_p()
-        call('mmft_event_create', ctypes.byref(h))
-        self.handle = h.value
-
-    def record(self, stream, external=True):
-        call('mmft_event_record', self.handle, int(external), self.device, stream.cuda_stream)
-
-    def wait(self, stream):
-        """Make `stream` wait for the most recent record of this event."""
-        call('mmft_stream_wait_event', stream.cuda_stream, self.handle, self.device)
-
-    def __del__(self):
-        try:
-            if self.handle and _lib is not None:
-                _lib.mmft_event_destroy(self.handle)
-        except Exception:                       # interpreter shutdown
-            pass
-
-
-def stream_is_capturing(stream, device):
-    return bool(query('mmft_stream_is_capturing', stream.cuda_stream, torch.device(device).index or 0))
-
-
 MATH_MODES = {'f32': 0, 'bf16': 1}
 
 

@@ -278,10 +278,8 @@ class GraphedTrainStep:
     step: the ~550 kernel launches of a step then cost no host time.  Per step the host only packs the sampled
     endpoints into a pinned int32 staging slot (one asynchronous H2D copy into a static device buffer); Adam's step
     counter lives on the device, so nothing else is uploaded.  Requires a constant number of sampled paths per step.  Under data parallelism the
-    graph holds forward + backward only: event-record nodes inside it tell the communication stream when a gradient
-    bucket is complete, and each bucket's RCCL all-reduce + Adam launch are issued eagerly behind the replay
-    (mmft.dist.GradReducer), so no collective is ever captured yet the head bucket is reduced under the rest of the
-    backward."""
+    graph holds forward + backward only; each gradient bucket's RCCL all-reduce + Adam launch are issued eagerly
+    behind the replay on the communication stream (mmft.dist.GradReducer), so no collective is ever captured."""
 
     def __init__(self, ts, example_path_ids, warmup=3):
         if not ts.fused or ts.mode != 'sweep':
@@ -321,9 +319,7 @@ class GraphedTrainStep:
             loss = mse_loss(hats, arrival)
             ts.optim.zero_grad()
             if ts.reducer is not None:
-                ts.reducer.begin(capturing=True)     # bucket-complete events become event-record nodes of the graph
-                loss.backward()
-                ts.reducer.end_capture()
+                loss.backward()                      # the buckets are reduced behind every replay (GradReducer)
             else:
                 loss.backward()
                 ts.optim.step_captured()
@@ -338,7 +334,7 @@ class GraphedTrainStep:
         ts.last_ends = sel[0]
         self.graph.replay()
         if ts.reducer is not None:
-            ts.reducer.after_replay()        # per bucket: wait for its in-graph event, all-reduce, Adam
+            ts.reducer.after_replay()        # per bucket: all-reduce + Adam on the communication stream
         else:
             ts.optim.note_replay()
         return self.loss, self.hats, sel[4].tolist()

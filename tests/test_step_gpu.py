@@ -257,48 +257,3 @@ def test_bench_self_launches_its_ranks(dev):
     j = json.loads(lines[0])
     assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['value'] > 0
     assert abs(j['value'] - 2 * 1 * 3 / (j['ms_per_step'] * 3 / 1e3)) / j['value'] < 1e-6      # whole-job designs / s
-
-
-def test_in_graph_event_orders_the_communication_stream(dev):
-    """What GradReducer relies on under graph replay: an event recorded by an event-record node INSIDE a captured graph
-    (mmft.lib.GraphEvent: hipEventRecordWithFlags + hipEventRecordExternal; torch.cuda.Event(external=True) is refused
-    on ROCm) orders a wait issued on another stream after the replay - and that stream runs while the rest of the graph
-    is still executing."""
-    from mmft import lib
-    n = 1 << 22
-    x = torch.zeros(n, device=dev)
-    big = torch.randn(4096, 4096, device=dev)
-    sink = torch.empty_like(big)
-    counter = torch.zeros(1, device=dev)
-    ev = lib.GraphEvent(dev)
-    side = torch.cuda.Stream(device=dev)
-    warm = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(warm):
-        torch.mm(big, big, out=sink)
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        counter += 1
-        x.copy_(counter.expand(n))                  # "gradient bucket complete"
-        ev.record(torch.cuda.current_stream(dev), external=True)
-        for _ in range(6):                          # the rest of the backward: a few ms of work
-            torch.mm(big, big, out=sink)
-    ys = torch.zeros(20, n // 1024, device=dev)
-    t_side, t_main = [], []
-    for i in range(20):
-        g.replay()
-        with torch.cuda.stream(side):
-            ev.wait(side)
-            ys[i].copy_(x[::1024])
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record(side)
-        e2 = torch.cuda.Event(enable_timing=True)
-        e2.record(torch.cuda.current_stream(dev))
-        torch.cuda.current_stream(dev).wait_stream(side)          # the next replay overwrites x
-        t_side.append(e1)
-        t_main.append(e2)
-    torch.cuda.synchronize()
-    want = torch.arange(1, 21, device=dev, dtype=torch.float32)[:, None].expand_as(ys)
-    assert torch.equal(ys, want), 'the side stream did not wait for the in-graph event'
-    lead = [e1.elapsed_time(e2) for e1, e2 in zip(t_side, t_main)]          # ms by which the side copy finished earlier
-    assert np.median(lead) > 0.2, lead
