@@ -47,7 +47,10 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(XL xl, WL wl, Epi epi, i
   constexpr int WG = WL::KMAJOR ? (BK / 8) * (BN / 4) : BN * (BK / 8);
   constexpr int XN = (XG + 255) / 256, WNL = (WG + 255) / 256;
   constexpr int XV = XL::KMAJOR ? 8 : 2, WV = WL::KMAJOR ? 8 : 2;      // 16-byte loads per group
-  __shared__ __attribute__((aligned(16))) unsigned short lds[2 * (XSZ + WSZ)];
+  // ONE LDS buffer: the multiply phase of a 64-deep step is ~0.2 us on the bf16 pipe, so a second buffer would buy
+  // nothing - what hides the HBM latency is the next step's loads in flight (registers) and the other workgroups of
+  // the CU (40 KB of LDS per 128x128 tile: the register budget, not LDS, sets the occupancy)
+  __shared__ __attribute__((aligned(16))) unsigned short lds[XSZ + WSZ];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -109,10 +112,14 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(XL xl, WL wl, Epi epi, i
 #pragma unroll
   for (int i = 0; i < XN; ++i) cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  f32x4 xr[XN][XV], wr[WNL][WV];
+  // register sets = K steps whose loads are in flight.  Measured at config B: a second set changes nothing for the
+  // 128x128 tiles (121 / 111 us either way - not latency-bound) and costs the narrow tiles their occupancy.
+  constexpr int PF = 1;
+  f32x4 xr[PF][XN][XV], wr[PF][WNL][WV];
   const bool x_in = has_fast<XL>::value && fast_interior(xl, m0, BM);
   const bool w_in = has_fast<WL>::value && fast_interior(wl, n0, BN);
-  auto gload = [&](int k0) {
+  auto gload = [&](auto setc, int k0) {
+    constexpr int S = decltype(setc)::value;
     // MK: two loads of 4 consecutive k; KM: eight loads, one per k row.  The interior / edge decision is made ONCE per
     // tile and operand (block-uniform): a per-load choice makes the compiler branch around every load and wait for
     // each one in turn.
@@ -122,14 +129,14 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(XL xl, WL wl, Epi epi, i
       for (int i = 0; i < XN; ++i)
         if (XG % 256 == 0 || tid + i * 256 < XG) {
 #pragma unroll
-          for (int v = 0; v < XV; ++v) xr[i][v] = fast_load(xl, xc[i], k0 + xk[i] + (XL::KMAJOR ? v : 4 * v), kend);
+          for (int v = 0; v < XV; ++v) xr[S][i][v] = fast_load(xl, xc[i], k0 + xk[i] + (XL::KMAJOR ? v : 4 * v), kend);
         }
     } else {
 #pragma unroll
       for (int i = 0; i < XN; ++i)
         if (XG % 256 == 0 || tid + i * 256 < XG) {
 #pragma unroll
-          for (int v = 0; v < XV; ++v) xr[i][v] = xl.load(xc[i], k0 + xk[i] + (XL::KMAJOR ? v : 4 * v), kend);
+          for (int v = 0; v < XV; ++v) xr[S][i][v] = xl.load(xc[i], k0 + xk[i] + (XL::KMAJOR ? v : 4 * v), kend);
         }
     }
     if (w_in && whole) {
@@ -137,14 +144,14 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(XL xl, WL wl, Epi epi, i
       for (int i = 0; i < WNL; ++i)
         if (WG % 256 == 0 || tid + i * 256 < WG) {
 #pragma unroll
-          for (int v = 0; v < WV; ++v) wr[i][v] = fast_load(wl, wc[i], k0 + wk[i] + (WL::KMAJOR ? v : 4 * v), kend);
+          for (int v = 0; v < WV; ++v) wr[S][i][v] = fast_load(wl, wc[i], k0 + wk[i] + (WL::KMAJOR ? v : 4 * v), kend);
         }
     } else {
 #pragma unroll
       for (int i = 0; i < WNL; ++i)
         if (WG % 256 == 0 || tid + i * 256 < WG) {
 #pragma unroll
-          for (int v = 0; v < WV; ++v) wr[i][v] = wl.load(wc[i], k0 + wk[i] + (WL::KMAJOR ? v : 4 * v), kend);
+          for (int v = 0; v < WV; ++v) wr[S][i][v] = wl.load(wc[i], k0 + wk[i] + (WL::KMAJOR ? v : 4 * v), kend);
         }
     }
   };
@@ -162,24 +169,25 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(XL xl, WL wl, Epi epi, i
       }
     }
   };
-  auto lstore = [&](int buf) {
-    unsigned short* xs = lds + buf * (XSZ + WSZ);
+  auto lstore = [&](auto setc) {
+    constexpr int S = decltype(setc)::value;
+    unsigned short* xs = lds;
     unsigned short* ws = xs + XSZ;
 #pragma unroll
     for (int i = 0; i < XN; ++i)
       if (XG % 256 == 0 || tid + i * 256 < XG) {
-        put(xs, xo[i], xr[i], XL::KMAJOR);
+        put(xs, xo[i], xr[S][i], XL::KMAJOR);
         if (XL::KMAJOR && do_cs) {
 #pragma unroll
-          for (int v = 0; v < 8; ++v) cs[i] += xr[i][v];
+          for (int v = 0; v < 8; ++v) cs[i] += xr[S][i][v];
         }
       }
 #pragma unroll
     for (int i = 0; i < WNL; ++i)
-      if (WG % 256 == 0 || tid + i * 256 < WG) put(ws, wo[i], wr[i], WL::KMAJOR);
+      if (WG % 256 == 0 || tid + i * 256 < WG) put(ws, wo[i], wr[S][i], WL::KMAJOR);
   };
-  auto multiply = [&](int buf) {
-    const unsigned short* xs = lds + buf * (XSZ + WSZ);
+  auto multiply = [&]() {
+    const unsigned short* xs = lds;
     const unsigned short* ws = xs + XSZ;
 #pragma unroll
     for (int kb = 0; kb < BK / 32; ++kb) {
@@ -198,16 +206,15 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(XL xl, WL wl, Epi epi, i
     }
   };
 
-  // global -> registers -> LDS, two LDS buffers, the next tile's loads in flight while the current one is multiplied
-  if (nk > 0) {
-    gload(kbeg);
-    lstore(0);
-  }
-  __syncthreads();
+  // global -> registers -> LDS -> MFMA.  Step t: registers (tile t, requested a whole step ago) go to LDS, the loads of
+  // tile t + 1 are issued at once and stay in flight across the multiply, the barrier and the wait of the next step.
+  using S0 = std::integral_constant<int, 0>;
+  if (nk > 0) gload(S0{}, kbeg);
   for (int t = 0; t < nk; ++t) {
-    if (t + 1 < nk) gload(kbeg + (t + 1) * BK);
-    multiply(t & 1);
-    if (t + 1 < nk) lstore((t + 1) & 1);
+    lstore(S0{});
+    __syncthreads();
+    if (t + 1 < nk) gload(S0{}, kbeg + (t + 1) * BK);
+    multiply();
     __syncthreads();
   }
 

@@ -676,9 +676,10 @@ inline void launch_cfg(const XL& xl, const WL& wl, const Epi& epi, int M, int N,
   // algorithmic work of this launch: 2*M*N*K flops; bytes = the three matrices touched once
   const double alg_bytes = operand_bytes(xl, M, K) + operand_bytes(wl, N, K) + 4.0 * (double)M * N;
   if (math_mode() == 1) {
-    // the bf16 MFMA consumes 32 k per instruction: the 16-deep tiles run with a 32-deep K step (same slab geometry,
-    // ksplit is a multiple of 16 and a K range that is not a multiple of BK ends in a zero-filled step)
-    using C2 = TileCfg<CFG::BM, CFG::BN, (CFG::BK < 32 ? 32 : CFG::BK), CFG::WM, CFG::WN>;
+    // every tile runs 64-deep K steps in this mode (two bf16 MFMAs of 32 k; 16 KB of fp32 operands per 128 rows and
+    // step in flight); the slab geometry is unchanged (ksplit is a multiple of 16, a K range that is not a multiple
+    // of 64 ends in a zero-filled step)
+    using C2 = TileCfg<CFG::BM, CFG::BN, 64, CFG::WM, CFG::WN>;
     MMFT_LAUNCH((gemm_bf16_kernel_name<C2, XL, WL>()), 2.0 * M * N * K, alg_bytes, (gemm_bf16_kernel<C2, XL, WL>), grid, dim3(256), st, xl, wl, epi, M, N, K, ksplit);
     return;
   }
