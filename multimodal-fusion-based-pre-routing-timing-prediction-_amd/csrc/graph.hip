@@ -141,6 +141,245 @@ __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Folded reverse sweep: ONE launch per (cell level l, net level l + 1) pair instead of one per level.
+//
+// A net-level node w has exactly one driver v (src/verilog_parser_asap7.py:1183-1188) and that driver sits one level
+// below it, so G[w] is needed by exactly one row of the level below: the thread group that owns v computes G[w] for
+// each of its sinks w on the fly (from DA / A / LSE of w's cell consumers, complete since two levels earlier), stores
+// it - the weight gradients of fc_net_self read it later - and adds it to its own sum.  Nothing is computed twice and
+// the level-serial chain is half as long.  Preconditions (checked once per graph on the host, mmft.pingraph): every
+// net in-degree is 1, every net edge goes from an even level l to level l + 1, cell-level nodes have no cell
+// out-edges; otherwise the per-level kernels are used.
+//
+// Driver fan-out is heavy-tailed (clock / reset nets): a row whose out-degree exceeds PAIR_HEAVY gets a whole
+// workgroup - eight thread groups stride over its sinks and their partial sums are combined through LDS in a fixed
+// order (bitwise reproducible) - instead of one 32-lane group walking hundreds of dependent row loads in series.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int PAIR_HEAVY = 16;
+
+// gradient of the pre-activation of net node w, channels c..c+3; stores it to G[w]
+__device__ __forceinline__ f32x4 net_node_grad(float* __restrict__ G, const float* __restrict__ h, long long ld, int w,
+                                               int c, const int* __restrict__ oc_ptr, const int* __restrict__ oc_idx,
+                                               const float* __restrict__ A, const float* __restrict__ LSE,
+                                               const float* __restrict__ DA, int relu,
+                                               const unsigned char* __restrict__ own) {
+  const long long off = (long long)w * ld + c;
+  int e = oc_ptr[w];
+  const int e1 = oc_ptr[w + 1];
+  const f32x4 hv = ld4(h + off);
+  f32x4 g = (!own || own[w]) ? ld4(G + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (; e + 2 <= e1; e += 2) {
+    long long o0 = (long long)oc_idx[e] * ld + c, o1 = (long long)oc_idx[e + 1] * ld + c;
+    f32x4 da0 = ld4(DA + o0), a0 = ld4(A + o0), l0 = ld4(LSE + o0);
+    f32x4 da1 = ld4(DA + o1), a1 = ld4(A + o1), l1 = ld4(LSE + o1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      g[j] += da0[j] * expf(hv[j] - l0[j]) * (1.0f + hv[j] - a0[j]);
+      g[j] += da1[j] * expf(hv[j] - l1[j]) * (1.0f + hv[j] - a1[j]);
+    }
+  }
+  for (; e < e1; ++e) {
+    long long wo = (long long)oc_idx[e] * ld + c;
+    f32x4 da = ld4(DA + wo), a = ld4(A + wo), l = ld4(LSE + wo);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] += da[j] * expf(hv[j] - l[j]) * (1.0f + hv[j] - a[j]);
+  }
+  if (relu) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] = hv[j] > 0.f ? g[j] : 0.f;
+  }
+  st4(G + off, g);
+  return g;
+}
+
+__global__ void __launch_bounds__(256) pair_bwd_pull_kernel(
+    float* __restrict__ G, const float* __restrict__ h, long long ld, const int* __restrict__ rows, int row0, int n, int D,
+    const int* __restrict__ on_ptr, const int* __restrict__ on_idx, const float* __restrict__ on_w,
+    const int* __restrict__ oc_ptr, const int* __restrict__ oc_idx, const float* __restrict__ A,
+    const float* __restrict__ LSE, const float* __restrict__ DA, int relu, const unsigned char* __restrict__ own,
+    const int* __restrict__ heavy, int nheavy, int light_blocks) {
+  __shared__ f32x4 part[8][64];                       // heavy rows: partial sums of the 8 thread groups (D <= 256)
+  const int groups = D >> 2;
+  if ((int)blockIdx.x >= light_blocks) {
+    // ---- heavy rows: one workgroup per row, the thread groups stride over the row's sinks
+    const int tgs = 256 / groups;                     // thread groups per workgroup (8 at D = 128)
+    const int tg = threadIdx.x / groups, c = (threadIdx.x - tg * groups) * 4;
+    for (int hi = (int)blockIdx.x - light_blocks; hi < nheavy; hi += (int)gridDim.x - light_blocks) {
+      const int v = heavy[hi];
+      const int e0 = on_ptr[v], e1 = on_ptr[v + 1];
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      const int act = tgs < 8 ? tgs : 8;              // thread groups that take part (LDS holds 8 partials)
+      if (tg < act) {
+        for (int e = e0 + tg; e < e1; e += act)
+          g += net_node_grad(G, h, ld, on_idx[e], c, oc_ptr, oc_idx, A, LSE, DA, relu, own) * on_w[e];
+        part[tg][c >> 2] = g;
+      }
+      __syncthreads();
+      if (tg == 0) {
+        const long long off = (long long)v * ld + c;
+        f32x4 s = (!own || own[v]) ? ld4(G + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < act; ++t) s += part[t][c >> 2];           // fixed order
+        if (relu) {
+          const f32x4 hv = ld4(h + off);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s[j] = hv[j] > 0.f ? s[j] : 0.f;
+        }
+        st4(G + off, s);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  // ---- light rows: one thread group per row
+  const long long total = (long long)n * groups;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)light_blocks * blockDim.x) {
+    int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
+    int v = rows ? rows[i] : row0 + i;
+    int e = on_ptr[v];
+    const int e1 = on_ptr[v + 1];
+    if (e1 - e > PAIR_HEAVY && heavy) continue;       // handled by a whole workgroup above
+    const long long off = (long long)v * ld + c;
+    f32x4 g = (!own || own[v]) ? ld4(G + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (; e < e1; ++e) g += net_node_grad(G, h, ld, on_idx[e], c, oc_ptr, oc_idx, A, LSE, DA, relu, own) * on_w[e];
+    if (relu) {
+      const f32x4 hv = ld4(h + off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = hv[j] > 0.f ? g[j] : 0.f;
+    }
+    st4(G + off, g);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Folded forward sweep: ONE gather launch per (net level l - 1, cell level l) pair.
+//   part A, net rows u of level l - 1:  h[u] = act(PRE[u] + mean_{d -> u} h[d])            (src/model.py:186-187,103-111)
+//   part B, cell rows v of level l:     A[v], LSE[v] = softmax-weighted sum over the in-neighbours (src/model.py:113-116),
+//           where an in-neighbour u of level l - 1 is NOT read from h (part A of this same launch is writing it) but
+//           recomputed from PRE[u] and its driver's row with the same instruction sequence - bitwise the value part A
+//           stores.  PRE holds fc_net_self(x_net) of the net rows (a buffer of its own, so that the in-place update of
+//           h cannot race with part B).  The net level must be the contiguous id range net_row0 .. net_row0 + n_net - 1.
+// Cell rows with more than PAIR_HEAVY in-edges (SRAM macros, config E's Zipf fan-in) get a whole workgroup: eight
+// thread groups stride over the edges with an online softmax each and their (max, sum, weighted sum) triples are merged
+// in a fixed order.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 net_node_value(const float* __restrict__ h, const float* __restrict__ PRE, long long ld,
+                                                int u, int c, const int* __restrict__ in_ptr,
+                                                const int* __restrict__ in_idx, int relu) {
+  const int e0 = in_ptr[u], e1 = in_ptr[u + 1];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int e = e0; e < e1; ++e) acc += ld4(h + (long long)in_idx[e] * ld + c);
+  if (e1 > e0) acc = acc * (1.0f / (float)(e1 - e0));
+  acc += ld4(PRE + (long long)u * ld + c);
+  if (relu) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = acc[j] > 0.f ? acc[j] : 0.f;
+  }
+  return acc;
+}
+
+struct SoftAcc {
+  f32x4 mx, s, acc;
+  __device__ __forceinline__ void init() {
+    mx = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    s = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc = s;
+  }
+  __device__ __forceinline__ void add(f32x4 x) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float m_new = fmaxf(mx[j], x[j]);
+      float scale = expf(mx[j] - m_new);
+      float p = expf(x[j] - m_new);
+      s[j] = s[j] * scale + p;
+      acc[j] = acc[j] * scale + p * x[j];
+      mx[j] = m_new;
+    }
+  }
+};
+
+__global__ void __launch_bounds__(256) pair_fwd_gather_kernel(
+    float* __restrict__ h, const float* __restrict__ PRE, long long ld, int D, const int* __restrict__ in_ptr,
+    const int* __restrict__ in_idx, const int* __restrict__ ic_ptr, const int* __restrict__ ic_idx, int net_row0, int n_net,
+    const int* __restrict__ rows, int cell_row0, int n_cell, float* __restrict__ A, float* __restrict__ LSE, long long lda,
+    int relu, const int* __restrict__ heavy, int nheavy, int light_blocks) {
+  __shared__ f32x4 pm[8][64], ps[8][64], pa[8][64];
+  const int groups = D >> 2;
+  if ((int)blockIdx.x >= light_blocks) {
+    const int tgs = 256 / groups, act = tgs < 8 ? tgs : 8;
+    const int tg = threadIdx.x / groups, c = (threadIdx.x - tg * groups) * 4;
+    for (int hi = (int)blockIdx.x - light_blocks; hi < nheavy; hi += (int)gridDim.x - light_blocks) {
+      const int v = heavy[hi];
+      const int e0 = ic_ptr[v], e1 = ic_ptr[v + 1];
+      if (tg < act) {
+        SoftAcc sa;
+        sa.init();
+        for (int e = e0 + tg; e < e1; e += act) {
+          const int u = ic_idx[e];
+          sa.add((unsigned)(u - net_row0) < (unsigned)n_net ? net_node_value(h, PRE, ld, u, c, in_ptr, in_idx, relu)
+                                                            : ld4(h + (long long)u * ld + c));
+        }
+        pm[tg][c >> 2] = sa.mx; ps[tg][c >> 2] = sa.s; pa[tg][c >> 2] = sa.acc;
+      }
+      __syncthreads();
+      if (tg == 0) {
+        f32x4 M = pm[0][c >> 2];
+        for (int t = 1; t < act; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) M[j] = fmaxf(M[j], pm[t][c >> 2][j]);
+        f32x4 S = {0.f, 0.f, 0.f, 0.f}, AC = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < act; ++t)                        // fixed order; empty partials carry max = -inf, sum = 0
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float sc = ps[t][c >> 2][j] > 0.f ? expf(pm[t][c >> 2][j] - M[j]) : 0.f;
+            S[j] += ps[t][c >> 2][j] * sc;
+            AC[j] += pa[t][c >> 2][j] * sc;
+          }
+        f32x4 a, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a[j] = AC[j] / S[j];
+          l[j] = M[j] + logf(S[j]);
+        }
+        st4(A + (long long)v * lda + c, a);
+        if (LSE) st4(LSE + (long long)v * lda + c, l);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  const long long total = (long long)(n_net + n_cell) * groups;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)light_blocks * blockDim.x) {
+    int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
+    if (i < n_net) {                                         // part A
+      const int u = net_row0 + i;
+      st4(h + (long long)u * ld + c, net_node_value(h, PRE, ld, u, c, in_ptr, in_idx, relu));
+      continue;
+    }
+    i -= n_net;                                              // part B
+    const int v = rows ? rows[i] : cell_row0 + i;
+    const int e0 = ic_ptr[v], e1 = ic_ptr[v + 1];
+    if (e1 - e0 > PAIR_HEAVY && heavy) continue;
+    SoftAcc sa;
+    sa.init();
+    for (int e = e0; e < e1; ++e) {
+      const int u = ic_idx[e];
+      sa.add((unsigned)(u - net_row0) < (unsigned)n_net ? net_node_value(h, PRE, ld, u, c, in_ptr, in_idx, relu)
+                                                        : ld4(h + (long long)u * ld + c));
+    }
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, l = {0.f, 0.f, 0.f, 0.f};
+    if (e1 > e0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a[j] = sa.acc[j] / sa.s[j];
+        l[j] = sa.mx[j] + logf(sa.s[j]);
+      }
+    }
+    st4(A + (long long)v * lda + c, a);
+    if (LSE) st4(LSE + (long long)v * lda + c, l);
+  }
+}
+
 // value = 1: zero the G rows of the sampled endpoints and flag them (the scatter-add of their gradients follows);
 // value = 0: clear the flags again.  Duplicated endpoints write the same values.
 __global__ void __launch_bounds__(256) target_rows_kernel(float* __restrict__ G, long long ld, const int* __restrict__ idx,
@@ -277,6 +516,53 @@ int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows,
               dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, G, h, ld, rows, row0, n, D, out_net_indptr,
               out_net_indices, out_net_weight, out_cell_indptr, out_cell_indices, A, LSE, DA, relu, own_mask);
   return check_launch("level_bwd_pull");
+}
+
+int mmft_pair_fwd_gather(float* h, const float* pre, long long ld, int D, const int* in_net_indptr,
+                         const int* in_net_indices, const int* in_cell_indptr, const int* in_cell_indices, int net_row0,
+                         int n_net, const int* cell_rows, int cell_row0, int n_cell, float* A, float* LSE, long long lda,
+                         int relu, const int* heavy_rows, int nheavy, long long alg_bytes, int device, void* stream) {
+  const int n = n_net + n_cell;
+  CHECK_ROWS("pair_fwd_gather");
+  MMFT_REQUIRE(n_net >= 0 && n_cell >= 0 && net_row0 >= 0 && cell_row0 >= 0, "pair_fwd_gather: negative row count / offset");
+  if (n == 0) return MMFT_OK;
+  MMFT_REQUIRE(h && pre && in_net_indptr && in_cell_indptr && (A || n_cell == 0), "pair_fwd_gather: null pointer");
+  MMFT_REQUIRE(ld >= D && ld % 4 == 0 && aligned16(h) && aligned16(pre) && (!A || (aligned16(A) && lda >= D && lda % 4 == 0)) &&
+                   (!LSE || aligned16(LSE)),
+               "pair_fwd_gather: rows must be 16-byte aligned");
+  MMFT_REQUIRE(D <= 256 && 256 % (D / 4) == 0, "pair_fwd_gather: D / 4 must divide 256 (D <= 256)");
+  MMFT_REQUIRE(nheavy >= 0 && (nheavy == 0 || heavy_rows), "pair_fwd_gather: heavy row list");
+  DeviceGuard dg(device);
+  const int light = node_grid(n, D);
+  const int hb = nheavy < 512 ? nheavy : 512;
+  MMFT_LAUNCH("pair_fwd_gather_kernel", 0.0, alg_bytes > 0 ? (double)alg_bytes : 3.0 * 4.0 * n * D, pair_fwd_gather_kernel,
+              dim3(light + hb), dim3(256), (hipStream_t)stream, h, pre, ld, D, in_net_indptr, in_net_indices, in_cell_indptr,
+              in_cell_indices, net_row0, n_net, cell_rows, cell_row0, n_cell, A, LSE, lda, relu,
+              nheavy ? heavy_rows : nullptr, nheavy, light);
+  return check_launch("pair_fwd_gather");
+}
+
+int mmft_pair_bwd_pull(float* G, const float* h, long long ld, const int* rows, int row0, int n, int D,
+                       const int* out_net_indptr, const int* out_net_indices, const float* out_net_weight,
+                       const int* out_cell_indptr, const int* out_cell_indices, const float* A, const float* LSE,
+                       const float* DA, int relu, const unsigned char* own_mask, const int* heavy_rows, int nheavy,
+                       long long alg_bytes, int device, void* stream) {
+  CHECK_ROWS("pair_bwd_pull");
+  MMFT_REQUIRE(G && h && out_net_indptr && out_cell_indptr && A && LSE && DA && (out_net_weight || n == 0),
+               "pair_bwd_pull: null pointer");
+  MMFT_REQUIRE(ld >= D && ld % 4 == 0 && aligned16(G) && aligned16(h) && aligned16(A) && aligned16(LSE) && aligned16(DA),
+               "pair_bwd_pull: rows must be 16-byte aligned");
+  MMFT_REQUIRE(D <= 256 && 256 % (D / 4) == 0, "pair_bwd_pull: D / 4 must divide 256 (D <= 256)");
+  MMFT_REQUIRE(nheavy >= 0 && (nheavy == 0 || heavy_rows), "pair_bwd_pull: heavy row list");
+  if (n == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  const int light = node_grid(n, D);
+  const int hb = nheavy < 512 ? nheavy : 512;
+  MMFT_LAUNCH("pair_bwd_pull_kernel", 0.0, alg_bytes > 0 ? (double)alg_bytes : 3.0 * 4.0 * n * D, pair_bwd_pull_kernel,
+              dim3(light + hb), dim3(256), (hipStream_t)stream, G, h, ld, rows, row0, n, D, out_net_indptr, out_net_indices,
+              out_net_weight, out_cell_indptr, out_cell_indices, A, LSE, DA, relu, own_mask, nheavy ? heavy_rows : nullptr,
+              nheavy, light);
+  return check_launch("pair_bwd_pull");
 }
 
 int mmft_target_rows_begin(float* G, long long ld, const int* idx, int n, int D, unsigned char* flags, int device,

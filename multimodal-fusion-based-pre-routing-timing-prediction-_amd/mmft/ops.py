@@ -354,6 +354,58 @@ def level_bwd_pull(G, h, rows, out_net, out_net_w, out_cell, A, LSE, DA, relu=Tr
     return G
 
 
+PAIR_HEAVY = 16        # rows with more edges than this get a whole workgroup in the folded level kernels (graph.hip)
+
+
+def pair_fwd_gather(h, pre, in_net, in_cell, net_range, cell_rows, A, LSE, relu=True, heavy=None, alg_bytes=0):
+    """Folded forward gather of one (net level, cell level) pair: see mmft_pair_fwd_gather in include/mmft.h.
+    net_range = (row0, n); cell_rows = int32 tensor | (row0, n) | None (no cell level)."""
+    _rows2d(h, 'h'); _rows2d(pre, 'pre')
+    N = h.shape[0]
+    if pre.shape != h.shape or pre.stride(0) != h.stride(0):
+        raise ValueError('pair_fwd_gather: pre must have the layout of h')
+    _csr(in_net[0], in_net[1], N, 'in_net'); _csr(in_cell[0], in_cell[1], N, 'in_cell')
+    _, nrow0, nn = _rowspec(net_range if net_range is not None else (0, 0), N, 'net_range')
+    if cell_rows is None:
+        ct, crow0, nc = None, 0, 0
+    else:
+        ct, crow0, nc = _rowspec(cell_rows, N, 'cell_rows')
+        _rows2d(A, 'A'); _rows2d(LSE, 'LSE')
+        if A.shape != h.shape or LSE.shape != h.shape or LSE.stride(0) != A.stride(0):
+            raise ValueError('pair_fwd_gather: A / LSE must match h')
+    if heavy is not None:
+        _idx(heavy, 'heavy')
+    dev, st = lib.stream_args(h)
+    lib.call('mmft_pair_fwd_gather', h, pre, h.stride(0), h.shape[1], in_net[0], in_net[1], in_cell[0], in_cell[1], nrow0, nn,
+             ct, crow0, nc, A if nc else None, LSE if nc else None, A.stride(0) if nc else h.stride(0), int(relu), heavy,
+             heavy.numel() if heavy is not None else 0, int(alg_bytes), dev, st)
+
+
+def pair_bwd_pull(G, h, rows, out_net, out_net_w, out_cell, A, LSE, DA, relu=True, own=None, heavy=None, alg_bytes=0):
+    """Folded reverse pull of one (cell level, following net level) pair: see mmft_pair_bwd_pull in include/mmft.h."""
+    for t, nm in ((G, 'G'), (h, 'h'), (A, 'A'), (LSE, 'LSE'), (DA, 'DA')):
+        _rows2d(t, nm)
+        if t.shape != h.shape or t.stride(0) != h.stride(0):
+            raise ValueError(f'pair_bwd_pull: {nm} must have the layout of h')
+    N = h.shape[0]
+    _csr(out_net[0], out_net[1], N, 'out_net'); _csr(out_cell[0], out_cell[1], N, 'out_cell')
+    _chk(out_net_w, 'out_net_w')
+    if out_net_w.numel() != out_net[1].numel() or not out_net_w.is_contiguous():
+        raise ValueError('pair_bwd_pull: one weight per out-net edge expected')
+    rt, row0, n = _rowspec(rows, N, 'rows')
+    if own is not None:
+        _chk(own, 'own', torch.uint8)
+        if own.numel() != N:
+            raise ValueError('pair_bwd_pull: one own-gradient flag per node expected')
+    if heavy is not None:
+        _idx(heavy, 'heavy')
+    dev, st = lib.stream_args(h)
+    lib.call('mmft_pair_bwd_pull', G, h, h.stride(0), rt, row0, n, h.shape[1], out_net[0], out_net[1], out_net_w,
+             out_cell[0], out_cell[1], A, LSE, DA, int(relu), own, heavy, heavy.numel() if heavy is not None else 0,
+             int(alg_bytes), dev, st)
+    return G
+
+
 def gather_rows(src, idx):
     _rows2d(src, 'src'); _idx(idx, 'idx')
     out = torch.empty((idx.numel(), src.shape[1]), dtype=torch.float32, device=src.device)

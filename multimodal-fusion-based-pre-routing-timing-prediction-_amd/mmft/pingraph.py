@@ -230,6 +230,47 @@ class PinGraph:
         self._level_cache[key] = ok
         return ok
 
+    def fold_schedule(self, level_nodes, heavy=16):
+        """Static facts for the folded level kernels (mmft_pair_fwd_gather / mmft_pair_bwd_pull), or None when the graph
+        does not meet their preconditions: a complete schedule, every net in-degree exactly 1, every net edge from an
+        even level l to level l + 1, every cell edge from an odd level, and every net level a contiguous id range.
+        Per level l: 'range', 'heavy_in' (cell rows with more than `heavy` cell in-edges), 'heavy_out' (rows with more
+        than `heavy` net out-edges) as device int32 tensors or None.  Cached per list object."""
+        if not self.level_set_is_complete(level_nodes):
+            return None
+        key = ('fold', tuple(id(n) for n in level_nodes), tuple(len(n) for n in level_nodes), heavy)
+        if key in self._level_cache:
+            return self._level_cache[key]
+        lev = np.full(self._n, -1, dtype=np.int64)
+        for l, nodes in enumerate(level_nodes):
+            lev[np.asarray(nodes, dtype=np.int64)] = l
+        ns, nd = self._coo['net']
+        cs, _cd = self._coo['cell']
+        in_net_deg = np.diff(self._csr_host[('in', 'net')][0])
+        ok = bool((in_net_deg[lev % 2 == 1] == 1).all()) and bool((in_net_deg[lev % 2 == 0] == 0).all())
+        if ns.size:
+            ok = ok and bool(((lev[ns] % 2 == 0) & (lev[nd] == lev[ns] + 1)).all())
+        if cs.size:
+            ok = ok and bool((lev[cs] % 2 == 1).all())
+        sched = None
+        if ok:
+            in_cell_deg = np.diff(self._csr_host[('in', 'cell')][0])
+            out_net_deg = np.diff(self._csr_host[('out', 'net')][0])
+            sched = []
+            for l, nodes in enumerate(level_nodes):
+                v = np.asarray(nodes, dtype=np.int64)
+                n = int(v.shape[0])
+                rng = (int(v[0]), n) if n and int(v[0]) + n - 1 == int(v[-1]) and bool((np.diff(v) == 1).all()) else None
+                if l % 2 == 1 and n and rng is None:
+                    sched = None                                  # the range test of the folded gather needs contiguous net levels
+                    break
+                dev_list = lambda a: torch.from_numpy(a.astype(np.int32)).to(self.device) if a.size else None
+                sched.append(dict(range=rng, n=n,
+                                  heavy_in=dev_list(v[in_cell_deg[v] > heavy]) if (l % 2 == 0 and n) else None,
+                                  heavy_out=dev_list(v[out_net_deg[v] > heavy]) if (l % 2 == 0 and n) else None))
+        self._level_cache[key] = sched
+        return sched
+
     # ------------------------------------------------------------------ construction helpers
     @staticmethod
     def from_synth(d, out_dim=None):

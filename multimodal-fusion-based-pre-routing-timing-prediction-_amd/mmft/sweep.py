@@ -56,6 +56,8 @@ class SweepState:
         self.next_level = 0
         self.bwd_active = False
         self.complete = False               # level lists = a complete schedule of the graph (whole-sweep entry)
+        self.fold = None                    # static facts for the folded level kernels (PinGraph.fold_schedule)
+        self.PRE = None
         self.target_order = None
         self.targets_unique = None
 
@@ -304,6 +306,7 @@ def level_forward(conv, graph, cur_nodes, targets, level_id):
 # wave per SIMD either way, and the software barrier over 252 workgroups (arrival skew of the slowest tile included)
 # costs more than the ~2 us hardware kernel boundary it replaces.  Off by default.
 PERSISTENT_FORWARD = False
+FOLD_LEVELS = True                  # folded level chain (one gather / one pull per level PAIR) when the graph allows it
 FUSED_FIRST_LAYER_GRADS = True      # mmft_mlp2_first_layer_grads for the *_self MLPs (False: dgrad GEMM + wgrad GEMM)
 
 
@@ -350,9 +353,12 @@ class SweepFn(torch.autograd.Function):
         if rc2 is not None:                                                              # fc_cell_self, all cell nodes
             _linear_rows(st.cell_feat, w1c, b1c, st.HS, rc2, act=ops.ACT_RELU)
             _linear_rows(st.HS, w2c, b2c, st.h, rc2)
+        fold = st.fold if (FOLD_LEVELS and not PERSISTENT_FORWARD) else None
+        if fold is not None:
+            st.PRE = st._buf('PRE', st.D)     # fc_net_self outputs live apart from h: the folded gather updates h in place
         if rn is not None:                                                               # fc_net_self, all net nodes
             _linear_rows(st.net_feat, w1n, b1n, st.HS, rn, act=ops.ACT_RELU)
-            _linear_rows(st.HS, w2n, b2n, st.h, rn)
+            _linear_rows(st.HS, w2n, b2n, st.PRE if fold is not None else st.h, rn)
         in_net, in_cell = g.csr('in', 'net'), g.csr('in', 'cell')
         persistent = PERSISTENT_FORWARD and ops.mlp2_fusable(st.D, st.Hd, st.D) and len(level_rows) > 1
         if persistent:
@@ -361,8 +367,26 @@ class SweepFn(torch.autograd.Function):
             ops.sweep_fwd_persistent(st.h, st.A, st.LSE, st.HN, in_net, in_cell, ps['ptr'], ps['rows'], len(level_rows),
                                      w1g, b1g, w2g, b2g, st.relu, ps['max_rows'], ps['counter'], ps['err'])
             ps['err_host'].copy_(ps['err'], non_blocking=True)
+        if fold is not None and not persistent:
+            # folded chain: one gather launch per (net level l - 1, cell level l) pair + the fused MLP of the cell level
+            L = len(level_rows)
+            for level_id in range(2, L + 1, 2):
+                net_l = level_id - 1
+                has_cell = level_id < L and level_rows[level_id].numel() > 0
+                if not has_cell and not fold[net_l]['n']:
+                    continue
+                meta_n = st.level_meta[net_l] if st.level_meta else None
+                meta_c = st.level_meta[level_id] if (st.level_meta and level_id < L) else None
+                crow = None
+                if has_cell:
+                    crow = fold[level_id]['range'] or level_rows[level_id]
+                ops.pair_fwd_gather(st.h, st.PRE, in_net, in_cell, fold[net_l]['range'] or (0, 0), crow, st.A, st.LSE,
+                                    relu=st.relu, heavy=fold[level_id]['heavy_in'] if has_cell else None,
+                                    alg_bytes=(meta_n['bytes_mean'] if meta_n else 0) + (meta_c['bytes_softmax'] if (meta_c and has_cell) else 0))
+                if has_cell:
+                    _cell_neigh_fwd(st, level_rows[level_id], w1g, b1g, w2g, b2g, act)
         for level_id, rows in enumerate(level_rows):
-            if persistent or level_id == 0 or not rows.numel():
+            if persistent or fold is not None or level_id == 0 or not rows.numel():
                 continue
             meta = st.level_meta[level_id] if st.level_meta else None
             spec = meta['range'] if (meta and meta['range']) else rows       # contiguous levels: no index array
@@ -393,8 +417,22 @@ class SweepFn(torch.autograd.Function):
         P = [_w(p) for p in st.params]
         w1g, w2g = P[8], P[10]
         out_net, out_cell, in_net_ptr = g.csr('out', 'net'), g.csr('out', 'cell'), g.out_net_weight()
+        fold = st.fold if (FOLD_LEVELS and not PERSISTENT_FORWARD) else None
+        if fold is not None:
+            # folded chain: one pull per (cell level l, net level l + 1) pair (the net rows are computed by their drivers)
+            for level_id, rows in reversed(st.levels):
+                if level_id % 2 == 1 or not rows.numel():
+                    continue
+                meta = st.level_meta[level_id] if st.level_meta else None
+                meta_n = st.level_meta[level_id + 1] if (st.level_meta and level_id + 1 < len(st.level_meta)) else None
+                spec = meta['range'] if (meta and meta['range']) else rows
+                ops.pair_bwd_pull(st.G, st.h, spec, out_net, in_net_ptr, out_cell, st.A, st.LSE, st.DA, relu=st.relu, own=own,
+                                  heavy=fold[level_id]['heavy_out'],
+                                  alg_bytes=(meta['bytes_pull'] if meta else 0) + (meta_n['bytes_pull'] if meta_n else 0))
+                if level_id > 0:
+                    _cell_neigh_bwd(st, rows, w1g, w2g, keep_dhn=True)
         for level_id, rows in reversed(st.levels):
-            if not rows.numel():
+            if fold is not None or not rows.numel():
                 continue
             meta = st.level_meta[level_id] if st.level_meta else None
             spec = meta['range'] if (meta and meta['range']) else rows
@@ -417,6 +455,7 @@ def sweep_forward_all(conv, graph, level_nodes, targets, target_order=None, targ
     st = SweepState(graph, conv)
     graph._sweep = st
     st.complete = graph.level_set_is_complete(level_nodes)
+    st.fold = graph.fold_schedule(level_nodes) if (FOLD_LEVELS and st.complete) else None
     st.target_order, st.targets_unique = target_order, targets_unique
     level_rows = [graph.level_rows(l, nodes, 'nodes') for l, nodes in enumerate(level_nodes)]
     st.level_meta = [graph.level_meta(l, nodes, st.D) if not torch.is_tensor(nodes) else None
