@@ -136,6 +136,11 @@ int mmft_seg_mean_add_act_fwd(float* h, long long ldh, const int* in_indptr, con
 int mmft_seg_sum_fwd(const float* src, long long lds, const int* indptr, const int* indices,
                      const int* rows, int n, int D, float* out, long long ldo, int accumulate,
                      int device, void* stream);
+/* the same sum with one WORKGROUP per row (thread groups stride over the segment, partials combined in a fixed order):
+ * for few, long segments - the gradient of PathModel.mlp_alpha's level table (src/model.py:267,280: one row per level,
+ * ~T/L endpoints each).  out[rows[i]] (rows == NULL: out[i]) */
+int mmft_seg_sum_rows_wg(const float* src, long long lds, const int* indptr, const int* indices, const int* rows, int n,
+                         int D, float* out, long long ldo, int accumulate, int device, void* stream);
 /* out[v] = mean_{u->v} src[u]  (standalone fn.mean) */
 int mmft_seg_mean_fwd(const float* src, long long lds, const int* in_indptr, const int* in_indices,
                       const int* rows, int n, int D, float* out, long long ldo, int device, void* stream);
@@ -149,31 +154,24 @@ int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows,
                         const int* out_net_indptr, const int* out_net_indices, const float* out_net_weight,
                         const int* out_cell_indptr, const int* out_cell_indices,
                         const float* A, const float* LSE, const float* DA, int relu, const unsigned char* own_mask,
-                        long long alg_bytes, int device, void* stream);
+                        const int* heavy_rows, int nheavy, int heavy_thresh, long long alg_bytes, int device,
+                        void* stream);
+/* heavy_rows (optional, nheavy of them): exactly the rows of this level whose out-degree (net + cell) exceeds
+ * heavy_thresh.  Each is reduced by a whole workgroup - eight thread groups stride over its out-edges, partial sums
+ * combined through LDS in a fixed order (deterministic) - instead of one 32-lane group walking hundreds of dependent
+ * row loads in series (drivers of clock / reset-like nets; config E's Zipf skew). */
 /* Folded forward sweep: one gather launch per (net level l - 1, cell level l) pair (src/model.py:185-204).
  *   net rows u = net_row0 .. net_row0 + n_net - 1:  h[u] = act(pre[u] + mean_{d->u} h[d])     (pre = fc_net_self(x_net))
  *   cell rows v (cell_rows[i] or cell_row0 + i):     A[v], LSE[v] as mmft_seg_softmax_sum_fwd, where in-neighbours inside
  *   the net range are recomputed from pre and their driver rows (bitwise the value stored by the first part) instead of
  *   being read from h - so the two levels need no launch boundary between them.  n_cell = 0 gives a plain net level.
- * heavy_rows (optional): the cell rows with more than 16 in-edges; each is reduced by a whole workgroup (partial online
- * softmaxes merged in a fixed order). */
+ * heavy_rows (optional): exactly the cell rows with more than heavy_thresh in-edges; each is reduced by a whole workgroup
+ * (partial online softmaxes merged in a fixed order), the others by one 32-lane thread group walking the edges in series. */
 int mmft_pair_fwd_gather(float* h, const float* pre, long long ld, int D, const int* in_net_indptr,
                          const int* in_net_indices, const int* in_cell_indptr, const int* in_cell_indices, int net_row0,
                          int n_net, const int* cell_rows, int cell_row0, int n_cell, float* A, float* LSE, long long lda,
-                         int relu, const int* heavy_rows, int nheavy, long long alg_bytes, int device, void* stream);
-/* Folded reverse sweep: the rows are the nodes v of an EVEN (cell) level l; for every sink w of v's net out-edges (w is
- * at level l + 1 and v is its only driver) the launch first computes and stores
- *   G[w] = mask_w( own(w) ? G[w] : 0  +  sum_{x in out_cell(w)} DA[x] * exp(h[w]-LSE[x]) * (1 + h[w] - A[x]) )
- * and then G[v] = mask_v( own(v) ? G[v] : 0 + sum_w G[w] * out_net_weight[e] ): two levels of mmft_level_bwd_pull in
- * one launch, half as many launches on the level-serial chain.  Valid when every net in-degree is 1, net edges go from
- * an even level to the next level and cell-level nodes have no cell out-edges (the caller checks).  heavy_rows
- * (optional): the rows of this level with more than 16 net out-edges; each gets a whole workgroup whose thread groups
- * stride over the sinks and combine their partial sums in a fixed order (deterministic). */
-int mmft_pair_bwd_pull(float* G, const float* h, long long ld, const int* rows, int row0, int n, int D,
-                       const int* out_net_indptr, const int* out_net_indices, const float* out_net_weight,
-                       const int* out_cell_indptr, const int* out_cell_indices, const float* A, const float* LSE,
-                       const float* DA, int relu, const unsigned char* own_mask, const int* heavy_rows, int nheavy,
-                       long long alg_bytes, int device, void* stream);
+                         int relu, const int* heavy_rows, int nheavy, int heavy_thresh, long long alg_bytes, int device,
+                         void* stream);
 /* own_mask (may be NULL): per-node flag telling whether G[v] already holds a gradient of its own (a sampled endpoint,
  * src/model.py:213); rows without the flag start from zero, so G needs no 4*N*D-byte fill per step.
  * mmft_target_rows_begin zeroes the G rows of the endpoints idx[0..n) and sets their flags (the scatter-add of the

@@ -89,10 +89,64 @@ __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
     float* __restrict__ G, const float* __restrict__ h, long long ld, const int* __restrict__ rows, int row0, int n,
     int D, const int* __restrict__ on_ptr, const int* __restrict__ on_idx, const float* __restrict__ on_w,
     const int* __restrict__ oc_ptr, const int* __restrict__ oc_idx, const float* __restrict__ A,
-    const float* __restrict__ LSE, const float* __restrict__ DA, int relu, const unsigned char* __restrict__ own) {
-  MMFT_NODE_LOOP(n, D) {
+    const float* __restrict__ LSE, const float* __restrict__ DA, int relu, const unsigned char* __restrict__ own,
+    const int* __restrict__ heavy, int nheavy, int light_blocks, int heavy_thresh) {
+  // Heavy rows (drivers of clock / reset-like nets, SRAM pins: out-degree in the hundreds) get a whole workgroup each:
+  // its thread groups stride over the row's out-edges and the partial sums are combined through LDS in a fixed order
+  // (bitwise reproducible).  One 32-lane group walking such a row in series is what set the duration of a level's
+  // launch (the light rows finish in a fraction of it).
+  __shared__ f32x4 part[8][64];
+  if ((int)blockIdx.x >= light_blocks) {
+    const int groups = D >> 2, tgs = 256 / groups, act = tgs < 8 ? tgs : 8;
+    const int tg = threadIdx.x / groups, c = (threadIdx.x - tg * groups) * 4;
+    for (int hi = (int)blockIdx.x - light_blocks; hi < nheavy; hi += (int)gridDim.x - light_blocks) {
+      const int v = heavy[hi];
+      const long long off = (long long)v * ld + c;
+      const f32x4 hv = ld4(h + off);
+      if (tg < act) {
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        const int e1 = on_ptr[v + 1];
+        int e = on_ptr[v] + tg;
+        for (; e + 3 * act < e1; e += 4 * act) {           // four edges of this group in flight
+          int w0 = on_idx[e], w1 = on_idx[e + act], w2 = on_idx[e + 2 * act], w3 = on_idx[e + 3 * act];
+          float s0 = on_w[e], s1 = on_w[e + act], s2 = on_w[e + 2 * act], s3 = on_w[e + 3 * act];
+          f32x4 r0 = ld4(G + (long long)w0 * ld + c), r1 = ld4(G + (long long)w1 * ld + c);
+          f32x4 r2 = ld4(G + (long long)w2 * ld + c), r3 = ld4(G + (long long)w3 * ld + c);
+          g += r0 * s0;
+          g += r1 * s1;
+          g += r2 * s2;
+          g += r3 * s3;
+        }
+        for (; e < e1; e += act) g += ld4(G + (long long)on_idx[e] * ld + c) * on_w[e];
+        const int c1 = oc_ptr[v + 1];
+        for (e = oc_ptr[v] + tg; e < c1; e += act) {
+          long long wo = (long long)oc_idx[e] * ld + c;
+          f32x4 da = ld4(DA + wo), a = ld4(A + wo), l = ld4(LSE + wo);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) g[j] += da[j] * expf(hv[j] - l[j]) * (1.0f + hv[j] - a[j]);
+        }
+        part[tg][c >> 2] = g;
+      }
+      __syncthreads();
+      if (tg == 0) {
+        f32x4 s = (!own || own[v]) ? ld4(G + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < act; ++t) s += part[t][c >> 2];           // fixed order
+        if (relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s[j] = hv[j] > 0.f ? s[j] : 0.f;
+        }
+        st4(G + off, s);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  const int groups = (D) >> 2;
+  const long long total = (long long)(n)*groups;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)light_blocks * blockDim.x) {
     int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
     int v = rows ? rows[i] : row0 + i;
+    if (heavy && (on_ptr[v + 1] - on_ptr[v]) + (oc_ptr[v + 1] - oc_ptr[v]) > heavy_thresh) continue;
     long long off = (long long)v * ld + c;
     // both edge ranges are requested up front: a node has net OR cell consumers, and the second pointer pair would
     // otherwise start its own dependent chain (pointer -> index -> row) only after the first loop
@@ -142,116 +196,6 @@ __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Folded reverse sweep: ONE launch per (cell level l, net level l + 1) pair instead of one per level.
-//
-// A net-level node w has exactly one driver v (src/verilog_parser_asap7.py:1183-1188) and that driver sits one level
-// below it, so G[w] is needed by exactly one row of the level below: the thread group that owns v computes G[w] for
-// each of its sinks w on the fly (from DA / A / LSE of w's cell consumers, complete since two levels earlier), stores
-// it - the weight gradients of fc_net_self read it later - and adds it to its own sum.  Nothing is computed twice and
-// the level-serial chain is half as long.  Preconditions (checked once per graph on the host, mmft.pingraph): every
-// net in-degree is 1, every net edge goes from an even level l to level l + 1, cell-level nodes have no cell
-// out-edges; otherwise the per-level kernels are used.
-//
-// Driver fan-out is heavy-tailed (clock / reset nets): a row whose out-degree exceeds PAIR_HEAVY gets a whole
-// workgroup - eight thread groups stride over its sinks and their partial sums are combined through LDS in a fixed
-// order (bitwise reproducible) - instead of one 32-lane group walking hundreds of dependent row loads in series.
-// ------------------------------------------------------------------------------------------------------------------
-constexpr int PAIR_HEAVY = 16;
-
-// gradient of the pre-activation of net node w, channels c..c+3; stores it to G[w]
-__device__ __forceinline__ f32x4 net_node_grad(float* __restrict__ G, const float* __restrict__ h, long long ld, int w,
-                                               int c, const int* __restrict__ oc_ptr, const int* __restrict__ oc_idx,
-                                               const float* __restrict__ A, const float* __restrict__ LSE,
-                                               const float* __restrict__ DA, int relu,
-                                               const unsigned char* __restrict__ own) {
-  const long long off = (long long)w * ld + c;
-  int e = oc_ptr[w];
-  const int e1 = oc_ptr[w + 1];
-  const f32x4 hv = ld4(h + off);
-  f32x4 g = (!own || own[w]) ? ld4(G + off) : f32x4{0.f, 0.f, 0.f, 0.f};
-  for (; e + 2 <= e1; e += 2) {
-    long long o0 = (long long)oc_idx[e] * ld + c, o1 = (long long)oc_idx[e + 1] * ld + c;
-    f32x4 da0 = ld4(DA + o0), a0 = ld4(A + o0), l0 = ld4(LSE + o0);
-    f32x4 da1 = ld4(DA + o1), a1 = ld4(A + o1), l1 = ld4(LSE + o1);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      g[j] += da0[j] * expf(hv[j] - l0[j]) * (1.0f + hv[j] - a0[j]);
-      g[j] += da1[j] * expf(hv[j] - l1[j]) * (1.0f + hv[j] - a1[j]);
-    }
-  }
-  for (; e < e1; ++e) {
-    long long wo = (long long)oc_idx[e] * ld + c;
-    f32x4 da = ld4(DA + wo), a = ld4(A + wo), l = ld4(LSE + wo);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) g[j] += da[j] * expf(hv[j] - l[j]) * (1.0f + hv[j] - a[j]);
-  }
-  if (relu) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) g[j] = hv[j] > 0.f ? g[j] : 0.f;
-  }
-  st4(G + off, g);
-  return g;
-}
-
-__global__ void __launch_bounds__(256) pair_bwd_pull_kernel(
-    float* __restrict__ G, const float* __restrict__ h, long long ld, const int* __restrict__ rows, int row0, int n, int D,
-    const int* __restrict__ on_ptr, const int* __restrict__ on_idx, const float* __restrict__ on_w,
-    const int* __restrict__ oc_ptr, const int* __restrict__ oc_idx, const float* __restrict__ A,
-    const float* __restrict__ LSE, const float* __restrict__ DA, int relu, const unsigned char* __restrict__ own,
-    const int* __restrict__ heavy, int nheavy, int light_blocks) {
-  __shared__ f32x4 part[8][64];                       // heavy rows: partial sums of the 8 thread groups (D <= 256)
-  const int groups = D >> 2;
-  if ((int)blockIdx.x >= light_blocks) {
-    // ---- heavy rows: one workgroup per row, the thread groups stride over the row's sinks
-    const int tgs = 256 / groups;                     // thread groups per workgroup (8 at D = 128)
-    const int tg = threadIdx.x / groups, c = (threadIdx.x - tg * groups) * 4;
-    for (int hi = (int)blockIdx.x - light_blocks; hi < nheavy; hi += (int)gridDim.x - light_blocks) {
-      const int v = heavy[hi];
-      const int e0 = on_ptr[v], e1 = on_ptr[v + 1];
-      f32x4 g = {0.f, 0.f, 0.f, 0.f};
-      const int act = tgs < 8 ? tgs : 8;              // thread groups that take part (LDS holds 8 partials)
-      if (tg < act) {
-        for (int e = e0 + tg; e < e1; e += act)
-          g += net_node_grad(G, h, ld, on_idx[e], c, oc_ptr, oc_idx, A, LSE, DA, relu, own) * on_w[e];
-        part[tg][c >> 2] = g;
-      }
-      __syncthreads();
-      if (tg == 0) {
-        const long long off = (long long)v * ld + c;
-        f32x4 s = (!own || own[v]) ? ld4(G + off) : f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < act; ++t) s += part[t][c >> 2];           // fixed order
-        if (relu) {
-          const f32x4 hv = ld4(h + off);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) s[j] = hv[j] > 0.f ? s[j] : 0.f;
-        }
-        st4(G + off, s);
-      }
-      __syncthreads();
-    }
-    return;
-  }
-  // ---- light rows: one thread group per row
-  const long long total = (long long)n * groups;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)light_blocks * blockDim.x) {
-    int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
-    int v = rows ? rows[i] : row0 + i;
-    int e = on_ptr[v];
-    const int e1 = on_ptr[v + 1];
-    if (e1 - e > PAIR_HEAVY && heavy) continue;       // handled by a whole workgroup above
-    const long long off = (long long)v * ld + c;
-    f32x4 g = (!own || own[v]) ? ld4(G + off) : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (; e < e1; ++e) g += net_node_grad(G, h, ld, on_idx[e], c, oc_ptr, oc_idx, A, LSE, DA, relu, own) * on_w[e];
-    if (relu) {
-      const f32x4 hv = ld4(h + off);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) g[j] = hv[j] > 0.f ? g[j] : 0.f;
-    }
-    st4(G + off, g);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // Folded forward sweep: ONE gather launch per (net level l - 1, cell level l) pair.
 //   part A, net rows u of level l - 1:  h[u] = act(PRE[u] + mean_{d -> u} h[d])            (src/model.py:186-187,103-111)
 //   part B, cell rows v of level l:     A[v], LSE[v] = softmax-weighted sum over the in-neighbours (src/model.py:113-116),
@@ -259,7 +203,7 @@ __global__ void __launch_bounds__(256) pair_bwd_pull_kernel(
 //           recomputed from PRE[u] and its driver's row with the same instruction sequence - bitwise the value part A
 //           stores.  PRE holds fc_net_self(x_net) of the net rows (a buffer of its own, so that the in-place update of
 //           h cannot race with part B).  The net level must be the contiguous id range net_row0 .. net_row0 + n_net - 1.
-// Cell rows with more than PAIR_HEAVY in-edges (SRAM macros, config E's Zipf fan-in) get a whole workgroup: eight
+// Cell rows with more than `heavy_thresh` in-edges (SRAM macros, config E's Zipf fan-in) get a whole workgroup: eight
 // thread groups stride over the edges with an online softmax each and their (max, sum, weighted sum) triples are merged
 // in a fixed order.
 // ------------------------------------------------------------------------------------------------------------------
@@ -302,7 +246,7 @@ __global__ void __launch_bounds__(256) pair_fwd_gather_kernel(
     float* __restrict__ h, const float* __restrict__ PRE, long long ld, int D, const int* __restrict__ in_ptr,
     const int* __restrict__ in_idx, const int* __restrict__ ic_ptr, const int* __restrict__ ic_idx, int net_row0, int n_net,
     const int* __restrict__ rows, int cell_row0, int n_cell, float* __restrict__ A, float* __restrict__ LSE, long long lda,
-    int relu, const int* __restrict__ heavy, int nheavy, int light_blocks) {
+    int relu, const int* __restrict__ heavy, int nheavy, int light_blocks, int heavy_thresh) {
   __shared__ f32x4 pm[8][64], ps[8][64], pa[8][64];
   const int groups = D >> 2;
   if ((int)blockIdx.x >= light_blocks) {
@@ -359,7 +303,7 @@ __global__ void __launch_bounds__(256) pair_fwd_gather_kernel(
     i -= n_net;                                              // part B
     const int v = rows ? rows[i] : cell_row0 + i;
     const int e0 = ic_ptr[v], e1 = ic_ptr[v + 1];
-    if (e1 - e0 > PAIR_HEAVY && heavy) continue;
+    if (e1 - e0 > heavy_thresh && heavy) continue;
     SoftAcc sa;
     sa.init();
     for (int e = e0; e < e1; ++e) {
@@ -435,6 +379,40 @@ __global__ void __launch_bounds__(256) scatter_add_rows_sorted_kernel(float* __r
   }
 }
 
+// out[rows[i]] (+)= sum over the CSR segment of row i of src[indices[e]] with ONE WORKGROUP per row: the thread groups
+// stride over the segment and their partial sums are combined through LDS in a fixed order.  For few, long segments
+// (the gradient of PathModel.mlp_alpha's level table: 64 rows x ~170 endpoints each) - one thread group per row walks
+// such a segment as a serial chain of dependent loads.
+__global__ void __launch_bounds__(256) seg_sum_wg_kernel(const float* __restrict__ src, long long lds_,
+                                                         const int* __restrict__ indptr, const int* __restrict__ indices,
+                                                         const int* __restrict__ rows, int n, int D,
+                                                         float* __restrict__ out, long long ldo, int accumulate) {
+  __shared__ f32x4 part[64][4];                        // up to 64 thread groups x 4 float4 channel groups (D <= 16)...
+  __shared__ f32x4 part2[8][64];                       // ...or 8 thread groups x 64 channel groups (D <= 256)
+  const int groups = D >> 2, tgs = 256 / groups;
+  const int tg = threadIdx.x / groups, cg = threadIdx.x - tg * groups, c = cg * 4;
+  const bool wide = groups > 4;
+  const int act = wide ? (tgs < 8 ? tgs : 8) : (tgs < 64 ? tgs : 64);
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int v = rows ? rows[i] : i;
+    const int e0 = indptr[v], e1 = indptr[v + 1];
+    if (tg < act) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int e = e0 + tg; e < e1; e += act) acc += ld4(src + (long long)indices[e] * lds_ + c);
+      if (wide) part2[tg][cg] = acc;
+      else part[tg][cg] = acc;
+    }
+    __syncthreads();
+    if (tg == 0) {
+      float* o = out + (long long)v * ldo + c;
+      f32x4 s = accumulate ? ld4(o) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < act; ++t) s += wide ? part2[t][cg] : part[t][cg];     // fixed order
+      st4(o, s);
+    }
+    __syncthreads();
+  }
+}
+
 static inline int node_grid(int n, int D) { return ew_grid((long long)n * (D / 4)); }
 
 }  // namespace mmft
@@ -487,6 +465,20 @@ int mmft_seg_mean_fwd(const float* src, long long lds, const int* in_indptr, con
   return check_launch("seg_mean_fwd");
 }
 
+int mmft_seg_sum_rows_wg(const float* src, long long lds, const int* indptr, const int* indices, const int* rows, int n,
+                         int D, float* out, long long ldo, int accumulate, int device, void* stream) {
+  CHECK_ROWS("seg_sum_rows_wg");
+  MMFT_REQUIRE(src && indptr && out, "seg_sum_rows_wg: null pointer");
+  MMFT_REQUIRE(lds >= D && ldo >= D && lds % 4 == 0 && ldo % 4 == 0 && aligned16(src) && aligned16(out),
+               "seg_sum_rows_wg: rows must be 16-byte aligned");
+  MMFT_REQUIRE(D <= 256 && 256 % (D / 4) == 0, "seg_sum_rows_wg: D / 4 must divide 256 (D <= 256)");
+  if (n == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  MMFT_LAUNCH("seg_sum_wg_kernel", 0.0, 0.0, seg_sum_wg_kernel, dim3(n < 2048 ? n : 2048), dim3(256), (hipStream_t)stream, src,
+              lds, indptr, indices, rows, n, D, out, ldo, accumulate);
+  return check_launch("seg_sum_rows_wg");
+}
+
 int mmft_seg_sum_fwd(const float* src, long long lds, const int* indptr, const int* indices, const int* rows, int n,
                      int D, float* out, long long ldo, int accumulate, int device, void* stream) {
   CHECK_ROWS("seg_sum_fwd");
@@ -502,9 +494,11 @@ int mmft_seg_sum_fwd(const float* src, long long lds, const int* indptr, const i
 int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows, int row0, int n, int D,
                         const int* out_net_indptr, const int* out_net_indices, const float* out_net_weight,
                         const int* out_cell_indptr, const int* out_cell_indices, const float* A, const float* LSE,
-                        const float* DA, int relu, const unsigned char* own_mask, long long alg_bytes, int device,
-                        void* stream) {
+                        const float* DA, int relu, const unsigned char* own_mask, const int* heavy_rows, int nheavy,
+                        int heavy_thresh, long long alg_bytes, int device, void* stream) {
   CHECK_ROWS("level_bwd_pull");
+  MMFT_REQUIRE(nheavy >= 0 && (nheavy == 0 || heavy_rows) && heavy_thresh >= 0, "level_bwd_pull: heavy row list");
+  MMFT_REQUIRE(nheavy == 0 || (D <= 256 && 256 % (D / 4) == 0), "level_bwd_pull: heavy rows need D / 4 to divide 256");
   MMFT_REQUIRE(G && h && out_net_indptr && out_cell_indptr && A && LSE && DA,
                "level_bwd_pull: null pointer");
   MMFT_REQUIRE(ld >= D && ld % 4 == 0 && aligned16(G) && aligned16(h) && aligned16(A) && aligned16(LSE) &&
@@ -512,16 +506,20 @@ int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows,
                "level_bwd_pull: rows must be 16-byte aligned");
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
+  const int light = node_grid(n, D);
+  const int hb = nheavy < 1024 ? nheavy : 1024;
   MMFT_LAUNCH("level_bwd_pull_kernel", 0.0, alg_bytes > 0 ? (double)alg_bytes : 3.0 * 4.0 * n * D, level_bwd_pull_kernel,
-              dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, G, h, ld, rows, row0, n, D, out_net_indptr,
-              out_net_indices, out_net_weight, out_cell_indptr, out_cell_indices, A, LSE, DA, relu, own_mask);
+              dim3(light + hb), dim3(256), (hipStream_t)stream, G, h, ld, rows, row0, n, D, out_net_indptr,
+              out_net_indices, out_net_weight, out_cell_indptr, out_cell_indices, A, LSE, DA, relu, own_mask,
+              nheavy ? heavy_rows : nullptr, nheavy, light, heavy_thresh);
   return check_launch("level_bwd_pull");
 }
 
 int mmft_pair_fwd_gather(float* h, const float* pre, long long ld, int D, const int* in_net_indptr,
                          const int* in_net_indices, const int* in_cell_indptr, const int* in_cell_indices, int net_row0,
                          int n_net, const int* cell_rows, int cell_row0, int n_cell, float* A, float* LSE, long long lda,
-                         int relu, const int* heavy_rows, int nheavy, long long alg_bytes, int device, void* stream) {
+                         int relu, const int* heavy_rows, int nheavy, int heavy_thresh, long long alg_bytes, int device,
+                         void* stream) {
   const int n = n_net + n_cell;
   CHECK_ROWS("pair_fwd_gather");
   MMFT_REQUIRE(n_net >= 0 && n_cell >= 0 && net_row0 >= 0 && cell_row0 >= 0, "pair_fwd_gather: negative row count / offset");
@@ -531,38 +529,15 @@ int mmft_pair_fwd_gather(float* h, const float* pre, long long ld, int D, const 
                    (!LSE || aligned16(LSE)),
                "pair_fwd_gather: rows must be 16-byte aligned");
   MMFT_REQUIRE(D <= 256 && 256 % (D / 4) == 0, "pair_fwd_gather: D / 4 must divide 256 (D <= 256)");
-  MMFT_REQUIRE(nheavy >= 0 && (nheavy == 0 || heavy_rows), "pair_fwd_gather: heavy row list");
+  MMFT_REQUIRE(nheavy >= 0 && (nheavy == 0 || heavy_rows) && heavy_thresh >= 0, "pair_fwd_gather: heavy row list");
   DeviceGuard dg(device);
   const int light = node_grid(n, D);
   const int hb = nheavy < 512 ? nheavy : 512;
   MMFT_LAUNCH("pair_fwd_gather_kernel", 0.0, alg_bytes > 0 ? (double)alg_bytes : 3.0 * 4.0 * n * D, pair_fwd_gather_kernel,
               dim3(light + hb), dim3(256), (hipStream_t)stream, h, pre, ld, D, in_net_indptr, in_net_indices, in_cell_indptr,
               in_cell_indices, net_row0, n_net, cell_rows, cell_row0, n_cell, A, LSE, lda, relu,
-              nheavy ? heavy_rows : nullptr, nheavy, light);
+              nheavy ? heavy_rows : nullptr, nheavy, light, heavy_thresh);
   return check_launch("pair_fwd_gather");
-}
-
-int mmft_pair_bwd_pull(float* G, const float* h, long long ld, const int* rows, int row0, int n, int D,
-                       const int* out_net_indptr, const int* out_net_indices, const float* out_net_weight,
-                       const int* out_cell_indptr, const int* out_cell_indices, const float* A, const float* LSE,
-                       const float* DA, int relu, const unsigned char* own_mask, const int* heavy_rows, int nheavy,
-                       long long alg_bytes, int device, void* stream) {
-  CHECK_ROWS("pair_bwd_pull");
-  MMFT_REQUIRE(G && h && out_net_indptr && out_cell_indptr && A && LSE && DA && (out_net_weight || n == 0),
-               "pair_bwd_pull: null pointer");
-  MMFT_REQUIRE(ld >= D && ld % 4 == 0 && aligned16(G) && aligned16(h) && aligned16(A) && aligned16(LSE) && aligned16(DA),
-               "pair_bwd_pull: rows must be 16-byte aligned");
-  MMFT_REQUIRE(D <= 256 && 256 % (D / 4) == 0, "pair_bwd_pull: D / 4 must divide 256 (D <= 256)");
-  MMFT_REQUIRE(nheavy >= 0 && (nheavy == 0 || heavy_rows), "pair_bwd_pull: heavy row list");
-  if (n == 0) return MMFT_OK;
-  DeviceGuard dg(device);
-  const int light = node_grid(n, D);
-  const int hb = nheavy < 512 ? nheavy : 512;
-  MMFT_LAUNCH("pair_bwd_pull_kernel", 0.0, alg_bytes > 0 ? (double)alg_bytes : 3.0 * 4.0 * n * D, pair_bwd_pull_kernel,
-              dim3(light + hb), dim3(256), (hipStream_t)stream, G, h, ld, rows, row0, n, D, out_net_indptr, out_net_indices,
-              out_net_weight, out_cell_indptr, out_cell_indices, A, LSE, DA, relu, own_mask, nheavy ? heavy_rows : nullptr,
-              nheavy, light);
-  return check_launch("pair_bwd_pull");
 }
 
 int mmft_target_rows_begin(float* G, long long ld, const int* idx, int n, int D, unsigned char* flags, int device,

@@ -9,6 +9,9 @@ from . import lib
 EPI_STORE, EPI_ACCUM, EPI_ADD_ACT = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 POOL_MAX, POOL_AVG = 0, 1
+# rows with more edges than this get a whole workgroup in the level kernels (graph.hip): a cell row's in-edges (forward
+# gather) / a node's out-edges (reverse pull) are a serial chain of dependent loads in one thread group otherwise
+PAIR_HEAVY_IN, PAIR_HEAVY_OUT = 16, 16
 
 
 def _chk(t, name, dtype=torch.float32):
@@ -313,8 +316,10 @@ def scatter_add_rows_det(dst, idx, src):
     sidx, perm = torch.sort(idx.long(), stable=True)
     indptr = torch.searchsorted(sidx, torch.arange(R + 1, device=idx.device)).to(torch.int32)
     dev, st = lib.stream_args(dst)
-    lib.call('mmft_seg_sum_fwd', src, src.stride(0), indptr, perm.to(torch.int32), None, R, dst.shape[1], dst,
-             dst.stride(0), 1, dev, st)
+    # few long segments (a 64-row level table fed by ~10^4 batch rows): a workgroup per destination row
+    name = 'mmft_seg_sum_rows_wg' if (idx.numel() >= 16 * R and dst.shape[1] <= 256 and 256 % (dst.shape[1] // 4) == 0) \
+        else 'mmft_seg_sum_fwd'
+    lib.call(name, src, src.stride(0), indptr, perm.to(torch.int32), None, R, dst.shape[1], dst, dst.stride(0), 1, dev, st)
     return dst
 
 
@@ -333,7 +338,8 @@ def target_rows_end(idx, flags):
     lib.call('mmft_target_rows_end', idx, idx.numel(), flags, dev, st)
 
 
-def level_bwd_pull(G, h, rows, out_net, out_net_w, out_cell, A, LSE, DA, relu=True, alg_bytes=0, own=None):
+def level_bwd_pull(G, h, rows, out_net, out_net_w, out_cell, A, LSE, DA, relu=True, alg_bytes=0, own=None, heavy=None,
+                   heavy_thresh=PAIR_HEAVY_OUT):
     for t, nm in ((G, 'G'), (h, 'h'), (A, 'A'), (LSE, 'LSE'), (DA, 'DA')):
         _rows2d(t, nm)
         if t.shape != h.shape or t.stride(0) != h.stride(0):
@@ -349,15 +355,18 @@ def level_bwd_pull(G, h, rows, out_net, out_net_w, out_cell, A, LSE, DA, relu=Tr
         if own.numel() != N:
             raise ValueError('level_bwd_pull: one own-gradient flag per node expected')
     dev, st = lib.stream_args(h)
+    if heavy is not None:
+        _idx(heavy, 'heavy')
     lib.call('mmft_level_bwd_pull', G, h, h.stride(0), rt, row0, n, h.shape[1], out_net[0], out_net[1], out_net_w,
-             out_cell[0], out_cell[1], A, LSE, DA, int(relu), own, int(alg_bytes), dev, st)
+             out_cell[0], out_cell[1], A, LSE, DA, int(relu), own, heavy, heavy.numel() if heavy is not None else 0,
+             int(heavy_thresh), int(alg_bytes), dev, st)
     return G
 
 
-PAIR_HEAVY = 16        # rows with more edges than this get a whole workgroup in the folded level kernels (graph.hip)
 
 
-def pair_fwd_gather(h, pre, in_net, in_cell, net_range, cell_rows, A, LSE, relu=True, heavy=None, alg_bytes=0):
+def pair_fwd_gather(h, pre, in_net, in_cell, net_range, cell_rows, A, LSE, relu=True, heavy=None, heavy_thresh=PAIR_HEAVY_IN,
+                    alg_bytes=0):
     """Folded forward gather of one (net level, cell level) pair: see mmft_pair_fwd_gather in include/mmft.h.
     net_range = (row0, n); cell_rows = int32 tensor | (row0, n) | None (no cell level)."""
     _rows2d(h, 'h'); _rows2d(pre, 'pre')
@@ -378,32 +387,7 @@ def pair_fwd_gather(h, pre, in_net, in_cell, net_range, cell_rows, A, LSE, relu=
     dev, st = lib.stream_args(h)
     lib.call('mmft_pair_fwd_gather', h, pre, h.stride(0), h.shape[1], in_net[0], in_net[1], in_cell[0], in_cell[1], nrow0, nn,
              ct, crow0, nc, A if nc else None, LSE if nc else None, A.stride(0) if nc else h.stride(0), int(relu), heavy,
-             heavy.numel() if heavy is not None else 0, int(alg_bytes), dev, st)
-
-
-def pair_bwd_pull(G, h, rows, out_net, out_net_w, out_cell, A, LSE, DA, relu=True, own=None, heavy=None, alg_bytes=0):
-    """Folded reverse pull of one (cell level, following net level) pair: see mmft_pair_bwd_pull in include/mmft.h."""
-    for t, nm in ((G, 'G'), (h, 'h'), (A, 'A'), (LSE, 'LSE'), (DA, 'DA')):
-        _rows2d(t, nm)
-        if t.shape != h.shape or t.stride(0) != h.stride(0):
-            raise ValueError(f'pair_bwd_pull: {nm} must have the layout of h')
-    N = h.shape[0]
-    _csr(out_net[0], out_net[1], N, 'out_net'); _csr(out_cell[0], out_cell[1], N, 'out_cell')
-    _chk(out_net_w, 'out_net_w')
-    if out_net_w.numel() != out_net[1].numel() or not out_net_w.is_contiguous():
-        raise ValueError('pair_bwd_pull: one weight per out-net edge expected')
-    rt, row0, n = _rowspec(rows, N, 'rows')
-    if own is not None:
-        _chk(own, 'own', torch.uint8)
-        if own.numel() != N:
-            raise ValueError('pair_bwd_pull: one own-gradient flag per node expected')
-    if heavy is not None:
-        _idx(heavy, 'heavy')
-    dev, st = lib.stream_args(h)
-    lib.call('mmft_pair_bwd_pull', G, h, h.stride(0), rt, row0, n, h.shape[1], out_net[0], out_net[1], out_net_w,
-             out_cell[0], out_cell[1], A, LSE, DA, int(relu), own, heavy, heavy.numel() if heavy is not None else 0,
-             int(alg_bytes), dev, st)
-    return G
+             heavy.numel() if heavy is not None else 0, int(heavy_thresh), int(alg_bytes), dev, st)
 
 
 def gather_rows(src, idx):

@@ -194,7 +194,13 @@ class PinGraph:
             rng = (int(v[0]), n)
         deg = lambda d, et: int((self._csr_host[(d, et)][0][v + 1] - self._csr_host[(d, et)][0][v]).sum()) if n else 0
         e_in_net, e_in_cell, e_out_net, e_out_cell = deg('in', 'net'), deg('in', 'cell'), deg('out', 'net'), deg('out', 'cell')
+        from . import ops
+        odeg = (self._csr_host[('out', 'net')][0][v + 1] - self._csr_host[('out', 'net')][0][v]) + \
+               (self._csr_host[('out', 'cell')][0][v + 1] - self._csr_host[('out', 'cell')][0][v]) if n else np.zeros(0, np.int64)
+        hv = v[odeg > ops.PAIR_HEAVY_OUT] if n else v
         meta = dict(range=rng, n=n,
+                    # rows whose out-degree exceeds ops.PAIR_HEAVY_OUT: reduced by a whole workgroup in the reverse pull
+                    heavy_out=torch.from_numpy(hv.astype(np.int32)).to(self.device) if hv.size else None,
                     bytes_mean=4 * D * (e_in_net + 2 * n) + 4 * e_in_net + 8 * n,
                     bytes_softmax=4 * D * (e_in_cell + 3 * n) + 4 * e_in_cell + 8 * n,
                     bytes_pull=4 * D * (e_out_net + 3 * e_out_cell + 3 * n) + 8 * e_out_net + 4 * e_out_cell + 16 * n)
@@ -230,15 +236,19 @@ class PinGraph:
         self._level_cache[key] = ok
         return ok
 
-    def fold_schedule(self, level_nodes, heavy=16):
+    def fold_schedule(self, level_nodes, heavy_in=None, heavy_out=None):
         """Static facts for the folded level kernels (mmft_pair_fwd_gather / mmft_pair_bwd_pull), or None when the graph
         does not meet their preconditions: a complete schedule, every net in-degree exactly 1, every net edge from an
         even level l to level l + 1, every cell edge from an odd level, and every net level a contiguous id range.
-        Per level l: 'range', 'heavy_in' (cell rows with more than `heavy` cell in-edges), 'heavy_out' (rows with more
-        than `heavy` net out-edges) as device int32 tensors or None.  Cached per list object."""
+        Per level l: 'range', 'heavy_in' (cell rows with more than `heavy_in` cell in-edges), 'heavy_out' (rows with more
+        than `heavy_out` net out-edges) as device int32 tensors or None; the thresholds default to ops.PAIR_HEAVY_IN /
+        ops.PAIR_HEAVY_OUT.  Cached per list object."""
+        from . import ops
+        heavy_in = ops.PAIR_HEAVY_IN if heavy_in is None else heavy_in
+        heavy_out = ops.PAIR_HEAVY_OUT if heavy_out is None else heavy_out
         if not self.level_set_is_complete(level_nodes):
             return None
-        key = ('fold', tuple(id(n) for n in level_nodes), tuple(len(n) for n in level_nodes), heavy)
+        key = ('fold', tuple(id(n) for n in level_nodes), tuple(len(n) for n in level_nodes), heavy_in, heavy_out)
         if key in self._level_cache:
             return self._level_cache[key]
         lev = np.full(self._n, -1, dtype=np.int64)
@@ -266,8 +276,8 @@ class PinGraph:
                     break
                 dev_list = lambda a: torch.from_numpy(a.astype(np.int32)).to(self.device) if a.size else None
                 sched.append(dict(range=rng, n=n,
-                                  heavy_in=dev_list(v[in_cell_deg[v] > heavy]) if (l % 2 == 0 and n) else None,
-                                  heavy_out=dev_list(v[out_net_deg[v] > heavy]) if (l % 2 == 0 and n) else None))
+                                  heavy_in=dev_list(v[in_cell_deg[v] > heavy_in]) if (l % 2 == 0 and n) else None,
+                                  heavy_out=dev_list(v[out_net_deg[v] > heavy_out]) if (l % 2 == 0 and n) else None))
         self._level_cache[key] = sched
         return sched
 

@@ -306,7 +306,7 @@ def level_forward(conv, graph, cur_nodes, targets, level_id):
 # wave per SIMD either way, and the software barrier over 252 workgroups (arrival skew of the slowest tile included)
 # costs more than the ~2 us hardware kernel boundary it replaces.  Off by default.
 PERSISTENT_FORWARD = False
-FOLD_LEVELS = True                  # folded level chain (one gather / one pull per level PAIR) when the graph allows it
+FOLD_LEVELS = True                  # folded forward chain (one gather per (net, cell) level PAIR) when the graph allows it
 FUSED_FIRST_LAYER_GRADS = True      # mmft_mlp2_first_layer_grads for the *_self MLPs (False: dgrad GEMM + wgrad GEMM)
 
 
@@ -417,27 +417,14 @@ class SweepFn(torch.autograd.Function):
         P = [_w(p) for p in st.params]
         w1g, w2g = P[8], P[10]
         out_net, out_cell, in_net_ptr = g.csr('out', 'net'), g.csr('out', 'cell'), g.out_net_weight()
-        fold = st.fold if (FOLD_LEVELS and not PERSISTENT_FORWARD) else None
-        if fold is not None:
-            # folded chain: one pull per (cell level l, net level l + 1) pair (the net rows are computed by their drivers)
-            for level_id, rows in reversed(st.levels):
-                if level_id % 2 == 1 or not rows.numel():
-                    continue
-                meta = st.level_meta[level_id] if st.level_meta else None
-                meta_n = st.level_meta[level_id + 1] if (st.level_meta and level_id + 1 < len(st.level_meta)) else None
-                spec = meta['range'] if (meta and meta['range']) else rows
-                ops.pair_bwd_pull(st.G, st.h, spec, out_net, in_net_ptr, out_cell, st.A, st.LSE, st.DA, relu=st.relu, own=own,
-                                  heavy=fold[level_id]['heavy_out'],
-                                  alg_bytes=(meta['bytes_pull'] if meta else 0) + (meta_n['bytes_pull'] if meta_n else 0))
-                if level_id > 0:
-                    _cell_neigh_bwd(st, rows, w1g, w2g, keep_dhn=True)
         for level_id, rows in reversed(st.levels):
-            if fold is not None or not rows.numel():
+            if not rows.numel():
                 continue
             meta = st.level_meta[level_id] if st.level_meta else None
             spec = meta['range'] if (meta and meta['range']) else rows
             ops.level_bwd_pull(st.G, st.h, spec, out_net, in_net_ptr, out_cell, st.A, st.LSE, st.DA, relu=st.relu,
-                               alg_bytes=meta['bytes_pull'] if meta else 0, own=own)
+                               alg_bytes=meta['bytes_pull'] if meta else 0, own=own,
+                               heavy=meta['heavy_out'] if meta else None)
             if level_id % 2 == 0 and level_id > 0:
                 _cell_neigh_bwd(st, rows, w1g, w2g, keep_dhn=True)
         grads = _batched_param_grads(st, P, dhn_ready=True) if ctx.nparams else []

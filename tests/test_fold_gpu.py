@@ -1,5 +1,5 @@
-"""Folded level chain (one gather launch per (net level, cell level) pair, one reverse pull per (cell level, net level)
-pair; heavy rows reduced by a whole workgroup): equal to the per-level kernels and to the fp64 oracle."""
+"""Folded forward chain (one gather launch per (net level, cell level) pair) and whole-workgroup reduction of heavy
+rows in the forward gather and the reverse pull: equal to the plain per-level kernels and to the fp64 oracle."""
 import numpy as np
 import pytest
 import torch
@@ -11,8 +11,12 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(pmodel, b, ends, fold):
-    from mmft import sweep as S
+    from mmft import sweep as S, ops
     S.FOLD_LEVELS = fold
+    keep = ops.PAIR_HEAVY_OUT
+    if not fold:                        # reference run: no folded gather, no heavy-row path in the reverse pull either
+        ops.PAIR_HEAVY_OUT = 1 << 30
+        b.graph._level_cache = {k: v for k, v in b.graph._level_cache.items() if not (isinstance(k, tuple) and k[0] == 'meta')}
     try:
         g = b.graph
         g.ndata['h'] = torch.zeros((b.N, 128), dtype=torch.float32, device=g.device)
@@ -25,6 +29,9 @@ def _run(pmodel, b, ends, fold):
                 {k: p.grad.clone() for k, p in pmodel.gnn.named_parameters() if p.grad is not None}, used)
     finally:
         S.FOLD_LEVELS = True
+        ops.PAIR_HEAVY_OUT = keep
+        if not fold:
+            b.graph._level_cache = {k: v for k, v in b.graph._level_cache.items() if not (isinstance(k, tuple) and k[0] == 'meta')}
 
 
 @pytest.mark.parametrize('fanin,N,L', [('regular', 6000, 12), ('irregular', 30000, 13), ('irregular', 30000, 16)])
@@ -38,7 +45,8 @@ def test_folded_chain_equals_per_level_kernels(dev, fanin, N, L):
     sched = b.graph.fold_schedule(b.level_nodes)
     assert sched is not None
     if fanin == 'irregular':
-        assert any(s['heavy_in'] is not None for s in sched) and any(s['heavy_out'] is not None for s in sched)
+        assert any(s['heavy_in'] is not None for s in sched)
+        assert any(b.graph.level_meta(l, nodes)['heavy_out'] is not None for l, nodes in enumerate(b.level_nodes))
     out_f, h_f, G_f, grads_f, used_f = _run(pmodel, b, ends, True)
     out_u, h_u, G_u, grads_u, used_u = _run(pmodel, b, ends, False)
     assert used_f and not used_u
