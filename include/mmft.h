@@ -144,6 +144,32 @@ int mmft_seg_sum_rows_wg(const float* src, long long lds, const int* indptr, con
 /* out[v] = mean_{u->v} src[u]  (standalone fn.mean) */
 int mmft_seg_mean_fwd(const float* src, long long lds, const int* in_indptr, const int* in_indices,
                       const int* rows, int n, int D, float* out, long long ldo, int device, void* stream);
+/* Attention branch of PathConv (flag_attn = True): message_func_attn + cell_msg_reduce_attn (src/model.py:119-136,
+ * 190-196).  fc_key = Linear(1, dk, no bias), fc_attn = Linear(2 dk, 1, no bias), so the edge score is
+ *   e(u -> v) = leaky_relu(c12[0] * key[u] + c12[1] * key[v], slope),  c12[0] = <fc_attn.w[:dk], fc_key.w>, c12[1] = <fc_attn.w[dk:], fc_key.w>
+ * (c12: two floats in DEVICE memory, computed by the caller with mmft_linear_fwd so that autograd reaches both weights).
+ *   alpha = softmax of e over the in-edges of v;  A[v] = sum alpha_i h[u_i]  (0 for degree 0);  alpha is stored per
+ *   in-edge (CSR position) for the reverse sweep. */
+int mmft_seg_attn_fwd(const float* h, long long ldh, const float* key, const float* c12, float slope, const int* in_indptr,
+                      const int* in_indices, const int* rows, int row0, int n, int D, float* A, long long lda, float* alpha,
+                      int device, void* stream);
+/* reverse pull of the attention branch: as mmft_level_bwd_pull with the cell term sum_{e: v->w} alpha[out2in_cell[e]] * DA[w]
+ * (out2in_cell maps an out-CSR edge position to the in-CSR position of the same edge) */
+int mmft_level_bwd_pull_attn(float* G, const float* h, long long ld, const int* rows, int row0, int n, int D,
+                             const int* out_net_indptr, const int* out_net_indices, const float* out_net_weight,
+                             const int* out_cell_indptr, const int* out_cell_indices, const int* out2in_cell,
+                             const float* alpha, const float* DA, int relu, const unsigned char* own_mask, int device,
+                             void* stream);
+/* gradient of the edge scores of the cell rows v: dcp[v][0..1] = sum_i da_i * (key[u_i], key[v]) with
+ * de_i = alpha_i (<DA[v], h[u_i]> - <DA[v], A[v]>), da_i = de_i * leaky_relu'(pre_i); the caller sums dcp over all rows
+ * (mmft_colsum) to obtain d loss / d c12.  D / 4 must be a power of two <= 64. */
+int mmft_seg_attn_bwd_scores(const float* DA, const float* h, const float* A, long long ld, const float* alpha,
+                             const float* key, const float* c12, float slope, const int* in_indptr, const int* in_indices,
+                             const int* rows, int row0, int n, int D, float* dcp, int device, void* stream);
+/* out[rows[i] (scatter) or i][0..D) = mean over the CSR segment of row rows[i] of src, any D: ndata['h_drive'] of the
+ * attention branch (fn.copy_src('net_feat') + fn.mean over the net in-edges, src/model.py:197-198,66-86) */
+int mmft_seg_mean_rows_any(const float* src, long long lds, const int* indptr, const int* indices, const int* rows, int n,
+                           int D, float* out, long long ldo, int scatter, int device, void* stream);
 /* Reverse sweep, one level (deterministic pull over out-edges, no atomics); out_net_weight[e] = 1/indeg_net of
  * the destination of out-edge e (static per graph, aligned with out_net_indices):
  *   gh = G[v] + sum_{e: v->w in out_net(v)} G[w] * out_net_weight[e]

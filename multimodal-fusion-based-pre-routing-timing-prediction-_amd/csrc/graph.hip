@@ -388,11 +388,11 @@ __global__ void __launch_bounds__(256) seg_sum_wg_kernel(const float* __restrict
                                                          const int* __restrict__ rows, int n, int D,
                                                          float* __restrict__ out, long long ldo, int accumulate) {
   __shared__ f32x4 part[64][4];                        // up to 64 thread groups x 4 float4 channel groups (D <= 16)...
-  __shared__ f32x4 part2[8][64];                       // ...or 8 thread groups x 64 channel groups (D <= 256)
+  __shared__ f32x4 part2[32][64];                      // ...or up to 32 thread groups x 64 channel groups (D <= 256)
   const int groups = D >> 2, tgs = 256 / groups;
   const int tg = threadIdx.x / groups, cg = threadIdx.x - tg * groups, c = cg * 4;
   const bool wide = groups > 4;
-  const int act = wide ? (tgs < 8 ? tgs : 8) : (tgs < 64 ? tgs : 64);
+  const int act = wide ? (tgs < 32 ? tgs : 32) : (tgs < 64 ? tgs : 64);
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     const int v = rows ? rows[i] : i;
     const int e0 = indptr[v], e1 = indptr[v + 1];
@@ -410,6 +410,129 @@ __global__ void __launch_bounds__(256) seg_sum_wg_kernel(const float* __restrict
       st4(o, s);
     }
     __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Attention branch of PathConv (flag_attn = True; src/model.py:56-58,119-136,190-198).
+//   message_func_attn:     e_i = leaky_relu(fc_attn([fc_key(key_u) || fc_key(key_v)]))    for the in-edge u_i -> v
+//   cell_msg_reduce_attn:  alpha = softmax_i(e_i);  A[v] = sum_i alpha_i h[u_i]            (one weight per EDGE)
+// fc_key is Linear(1, 256, no bias) and fc_attn Linear(512, 1, no bias), so the score is e_i = leaky_relu(c1 key_u +
+// c2 key_v) with c1 = <fc_attn.w[:256], fc_key.w>, c2 = <fc_attn.w[256:], fc_key.w>: the host computes the two scalars
+// with the dense kernels (so autograd carries their gradient back into both parameters) and hands them over in
+// device memory.  alpha is kept per in-edge (CSR position) for the reverse sweep.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.f ? x : x * slope; }
+
+__global__ void __launch_bounds__(256) seg_attn_fwd_kernel(const float* __restrict__ h, long long ldh,
+                                                           const float* __restrict__ key, const float* __restrict__ cc,
+                                                           float slope, const int* __restrict__ indptr,
+                                                           const int* __restrict__ indices, const int* __restrict__ rows,
+                                                           int row0, int n, int D, float* __restrict__ A, long long lda,
+                                                           float* __restrict__ alpha) {
+  const float c1 = cc[0], c2 = cc[1];
+  MMFT_NODE_LOOP(n, D) {
+    int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
+    int v = rows ? rows[i] : row0 + i;
+    const int e0 = indptr[v], e1 = indptr[v + 1];
+    const float cv = c2 * key[v];
+    float mx = -INFINITY;
+    for (int e = e0; e < e1; ++e) mx = fmaxf(mx, lrelu(c1 * key[indices[e]] + cv, slope));
+    float ssum = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int e = e0; e < e1; ++e) {
+      const int u = indices[e];
+      const float p = expf(lrelu(c1 * key[u] + cv, slope) - mx);
+      ssum += p;
+      acc += ld4(h + (long long)u * ldh + c) * p;
+    }
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (e1 > e0) {
+      const float inv = 1.0f / ssum;
+      a = acc * inv;
+      if (c == 0)
+        for (int e = e0; e < e1; ++e) alpha[e] = expf(lrelu(c1 * key[indices[e]] + cv, slope) - mx) * inv;
+    }
+    st4(A + (long long)v * lda + c, a);
+  }
+}
+
+// reverse pull with per-edge attention weights: G[v] = mask( own + sum_{net out} G[w] wgt + sum_{cell out e} alpha[o2i[e]] DA[w] )
+__global__ void __launch_bounds__(256) level_bwd_pull_attn_kernel(
+    float* __restrict__ G, const float* __restrict__ h, long long ld, const int* __restrict__ rows, int row0, int n, int D,
+    const int* __restrict__ on_ptr, const int* __restrict__ on_idx, const float* __restrict__ on_w,
+    const int* __restrict__ oc_ptr, const int* __restrict__ oc_idx, const int* __restrict__ o2i,
+    const float* __restrict__ alpha, const float* __restrict__ DA, int relu, const unsigned char* __restrict__ own) {
+  MMFT_NODE_LOOP(n, D) {
+    int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
+    int v = rows ? rows[i] : row0 + i;
+    const long long off = (long long)v * ld + c;
+    f32x4 g = (!own || own[v]) ? ld4(G + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int e = on_ptr[v]; e < on_ptr[v + 1]; ++e) g += ld4(G + (long long)on_idx[e] * ld + c) * on_w[e];
+    for (int e = oc_ptr[v]; e < oc_ptr[v + 1]; ++e) g += ld4(DA + (long long)oc_idx[e] * ld + c) * alpha[o2i[e]];
+    if (relu) {
+      const f32x4 hv = ld4(h + off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = hv[j] > 0.f ? g[j] : 0.f;
+    }
+    st4(G + off, g);
+  }
+}
+
+// gradient of the edge scores of one cell level: dcp[v] = (sum_i da_i key_u, sum_i da_i key_v) with
+//   de_i = alpha_i (<DA[v], h[u_i]> - <DA[v], A[v]>),  da_i = de_i * leaky_relu'(c1 key_u + c2 key_v)
+// (D / 4 lanes of a node reduce their channel shares with xor shuffles: D / 4 must be a power of two <= 64)
+__global__ void __launch_bounds__(256) seg_attn_bwd_scores_kernel(
+    const float* __restrict__ DA, const float* __restrict__ h, const float* __restrict__ A, long long ld,
+    const float* __restrict__ alpha, const float* __restrict__ key, const float* __restrict__ cc, float slope,
+    const int* __restrict__ indptr, const int* __restrict__ indices, const int* __restrict__ rows, int row0, int n, int D,
+    float* __restrict__ dcp) {
+  const float c1 = cc[0], c2 = cc[1];
+  const int groups = D >> 2;
+  const long long total = (long long)n * groups;
+  // every lane of a wave takes part in the shuffles: loop bounds are rounded up to whole thread groups (always true
+  // here since total is a multiple of groups and groups divides the block size)
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
+    int v = rows ? rows[i] : row0 + i;
+    const f32x4 da = ld4(DA + (long long)v * ld + c), av = ld4(A + (long long)v * ld + c);
+    float tpart = da.x * av.x + da.y * av.y + da.z * av.z + da.w * av.w;
+    for (int m = 1; m < groups; m <<= 1) tpart += __shfl_xor(tpart, m, 64);
+    const float kv = key[v];
+    float p1 = 0.f, p2 = 0.f;
+    for (int e = indptr[v]; e < indptr[v + 1]; ++e) {
+      const int u = indices[e];
+      const f32x4 hu = ld4(h + (long long)u * ld + c);
+      float sp = da.x * hu.x + da.y * hu.y + da.z * hu.z + da.w * hu.w;
+      for (int m = 1; m < groups; m <<= 1) sp += __shfl_xor(sp, m, 64);
+      const float ku = key[u];
+      const float pre = c1 * ku + c2 * kv;
+      const float dai = alpha[e] * (sp - tpart) * (pre > 0.f ? 1.0f : slope);
+      p1 += dai * ku;
+      p2 += dai * kv;
+    }
+    if (c == 0) {
+      dcp[(long long)v * 2] = p1;
+      dcp[(long long)v * 2 + 1] = p2;
+    }
+  }
+}
+
+// out[rows[i] or i][0..D) = mean over the CSR segment of src rows, any D (one thread per element): ndata['h_drive'] of the
+// attention branch (src/model.py:197-198: fn.copy_src('net_feat') + fn.mean, D = net_feat_dim = 2)
+__global__ void __launch_bounds__(256) seg_mean_any_kernel(const float* __restrict__ src, long long lds_,
+                                                           const int* __restrict__ indptr, const int* __restrict__ indices,
+                                                           const int* __restrict__ rows, int n, int D,
+                                                           float* __restrict__ out, long long ldo, int scatter) {
+  const long long total = (long long)n * D;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    int i = (int)(t / D), c = (int)(t - (long long)i * D);
+    int v = rows ? rows[i] : i;
+    const int e0 = indptr[v], e1 = indptr[v + 1];
+    float acc = 0.f;
+    for (int e = e0; e < e1; ++e) acc += src[(long long)indices[e] * lds_ + c];
+    if (e1 > e0) acc = acc / (float)(e1 - e0);
+    out[(long long)(scatter ? v : i) * ldo + c] = acc;
   }
 }
 
@@ -463,6 +586,64 @@ int mmft_seg_mean_fwd(const float* src, long long lds, const int* in_indptr, con
   DeviceGuard dg(device);
   MMFT_LAUNCH("seg_mean_fwd_kernel", 0.0, 3.0 * 4.0 * n * D, seg_mean_fwd_kernel, dim3(node_grid(n, D)), dim3(256), (hipStream_t)stream, src, lds, in_indptr, in_indices, rows, 0, n, D, out, ldo, 0, 0, 1);
   return check_launch("seg_mean_fwd");
+}
+
+int mmft_seg_attn_fwd(const float* h, long long ldh, const float* key, const float* c12, float slope, const int* in_indptr,
+                      const int* in_indices, const int* rows, int row0, int n, int D, float* A, long long lda, float* alpha,
+                      int device, void* stream) {
+  CHECK_ROWS("seg_attn_fwd");
+  if (n == 0) return MMFT_OK;
+  MMFT_REQUIRE(h && key && c12 && in_indptr && A && alpha, "seg_attn_fwd: null pointer");
+  MMFT_REQUIRE(ldh >= D && lda >= D && ldh % 4 == 0 && lda % 4 == 0 && aligned16(h) && aligned16(A),
+               "seg_attn_fwd: rows must be 16-byte aligned");
+  DeviceGuard dg(device);
+  MMFT_LAUNCH("seg_attn_fwd_kernel", 0.0, 3.0 * 4.0 * n * D, seg_attn_fwd_kernel, dim3(node_grid(n, D)), dim3(256),
+              (hipStream_t)stream, h, ldh, key, c12, slope, in_indptr, in_indices, rows, row0, n, D, A, lda, alpha);
+  return check_launch("seg_attn_fwd");
+}
+
+int mmft_level_bwd_pull_attn(float* G, const float* h, long long ld, const int* rows, int row0, int n, int D,
+                             const int* out_net_indptr, const int* out_net_indices, const float* out_net_weight,
+                             const int* out_cell_indptr, const int* out_cell_indices, const int* out2in_cell,
+                             const float* alpha, const float* DA, int relu, const unsigned char* own_mask, int device,
+                             void* stream) {
+  CHECK_ROWS("level_bwd_pull_attn");
+  if (n == 0) return MMFT_OK;
+  MMFT_REQUIRE(G && h && out_net_indptr && out_cell_indptr && DA, "level_bwd_pull_attn: null pointer");
+  MMFT_REQUIRE(ld >= D && ld % 4 == 0 && aligned16(G) && aligned16(h) && aligned16(DA),
+               "level_bwd_pull_attn: rows must be 16-byte aligned");
+  DeviceGuard dg(device);
+  MMFT_LAUNCH("level_bwd_pull_attn_kernel", 0.0, 3.0 * 4.0 * n * D, level_bwd_pull_attn_kernel, dim3(node_grid(n, D)),
+              dim3(256), (hipStream_t)stream, G, h, ld, rows, row0, n, D, out_net_indptr, out_net_indices, out_net_weight,
+              out_cell_indptr, out_cell_indices, out2in_cell, alpha, DA, relu, own_mask);
+  return check_launch("level_bwd_pull_attn");
+}
+
+int mmft_seg_attn_bwd_scores(const float* DA, const float* h, const float* A, long long ld, const float* alpha,
+                             const float* key, const float* c12, float slope, const int* in_indptr, const int* in_indices,
+                             const int* rows, int row0, int n, int D, float* dcp, int device, void* stream) {
+  CHECK_ROWS("seg_attn_bwd_scores");
+  if (n == 0) return MMFT_OK;
+  MMFT_REQUIRE(DA && h && A && alpha && key && c12 && in_indptr && dcp, "seg_attn_bwd_scores: null pointer");
+  const int groups = D / 4;
+  MMFT_REQUIRE(groups <= 64 && (groups & (groups - 1)) == 0, "seg_attn_bwd_scores: D / 4 must be a power of two <= 64");
+  MMFT_REQUIRE(ld >= D && ld % 4 == 0 && aligned16(DA) && aligned16(h) && aligned16(A),
+               "seg_attn_bwd_scores: rows must be 16-byte aligned");
+  DeviceGuard dg(device);
+  MMFT_LAUNCH("seg_attn_bwd_scores_kernel", 0.0, 3.0 * 4.0 * n * D, seg_attn_bwd_scores_kernel, dim3(node_grid(n, D)),
+              dim3(256), (hipStream_t)stream, DA, h, A, ld, alpha, key, c12, slope, in_indptr, in_indices, rows, row0, n, D, dcp);
+  return check_launch("seg_attn_bwd_scores");
+}
+
+int mmft_seg_mean_rows_any(const float* src, long long lds, const int* indptr, const int* indices, const int* rows, int n,
+                           int D, float* out, long long ldo, int scatter, int device, void* stream) {
+  MMFT_REQUIRE(n >= 0 && D > 0 && lds >= D && ldo >= D, "seg_mean_rows_any: bad sizes");
+  if (n == 0) return MMFT_OK;
+  MMFT_REQUIRE(src && indptr && out, "seg_mean_rows_any: null pointer");
+  DeviceGuard dg(device);
+  hipLaunchKernelGGL(seg_mean_any_kernel, dim3(ew_grid((long long)n * D)), dim3(256), 0, (hipStream_t)stream, src, lds, indptr,
+                     indices, rows, n, D, out, ldo, scatter);
+  return check_launch("seg_mean_rows_any");
 }
 
 int mmft_seg_sum_rows_wg(const float* src, long long lds, const int* indptr, const int* indices, const int* rows, int n,

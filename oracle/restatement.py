@@ -12,7 +12,8 @@ What each function follows (paths relative to /root/reference):
   mlp                 src/model.py:10-24      Linear -> LeakyReLU(slope) -> ... -> Linear
   seg_softmax_sum     src/model.py:113-116    per-channel softmax-weighted sum over the mailbox
   seg_mean            src/model.py:186-187    fn.copy_src + fn.mean  (0 for zero in-degree)
-  pathconv_level      src/model.py:158-213    one PathConv.forward call (net / cell / level 0)
+  seg_attn_sum        src/model.py:119-136    attention branch: edge score + softmax over in-edges + weighted sum
+  pathconv_level      src/model.py:158-213    one PathConv.forward call (net / cell / level 0 / attention)
   pathmodel_level     src/model.py:269-292    one PathModel.forward call
   unet_forward        src/Unet.py:8-119       DoubleConv/Down/Up/OutConv/UNet, BN in train mode
   layoutnet_forward   src/model.py:216-247
@@ -82,12 +83,37 @@ def seg_softmax_sum(h, indptr, indices, nodes):
     return out
 
 
+def seg_attn_sum(h, key, indptr, indices, nodes, w_key, w_attn):
+    """The attention branch's cell pull (src/model.py:119-136,190-196) over DGL's degree buckets:
+    message_func_attn: z = cat([fc_key(key_src), fc_key(key_dst)], 1); e = leaky_relu(fc_attn(z))   (slope 0.01)
+    cell_msg_reduce_attn: alpha = softmax(e, dim=1) over the in-edges; h_neigh1 = sum(alpha * m, 1), m = h_src.
+    w_key = fc_key.weight (dim_key, 1), w_attn = fc_attn.weight (1, 2 * dim_key); zero rows for degree 0."""
+    nodes = np.asarray(nodes, dtype=np.int64)
+    start, deg = _in_edges(indptr, indices, nodes)
+    out = h.new_zeros((len(nodes), h.shape[1]))
+    for d in np.unique(deg):
+        if d == 0:
+            continue
+        sel = np.nonzero(deg == d)[0]
+        eid = start[sel][:, None] + np.arange(d)[None, :]
+        src = torch.from_numpy(indices[eid])                                   # (n_bucket, d)
+        dst = torch.from_numpy(np.repeat(nodes[sel][:, None], d, axis=1))
+        z = torch.cat([F.linear(key[src], w_key), F.linear(key[dst], w_key)], dim=-1)       # (n, d, 2 * dim_key)
+        e = F.leaky_relu(F.linear(z, w_attn))                                  # (n, d, 1)
+        alpha = torch.softmax(e, dim=1)
+        out = out.index_copy(0, torch.from_numpy(sel), (alpha * h[src]).sum(1))
+    return out
+
+
 # --------------------------------------------------------------------------- PathConv.forward
-def pathconv_level(p, prefix, csr, h, cell_feat, net_feat, cur_nodes, targets, level_id, activation=True):
+def pathconv_level(p, prefix, csr, h, cell_feat, net_feat, cur_nodes, targets, level_id, activation=True, key=None):
     """One call of PathConv.forward (src/model.py:158-213). Returns (h_new, h_new[targets]).
 
     csr = {'net': (indptr, indices), 'cell': (indptr, indices)} numpy int64, in-edges by dst.
     `h` is treated functionally (DGL's frame update is out of place too).
+    key (N, 1): ndata['key'] -> the flag_attn=True branch (src/model.py:190-198); its second pull only fills
+    ndata['h_drive'] (mean of net_feat over net in-edges, src/model.py:197-198,66-86), which nothing reads - see
+    pathconv_h_drive.
     """
     idx = torch.as_tensor(np.asarray(cur_nodes, dtype=np.int64))
     if len(cur_nodes):
@@ -96,6 +122,11 @@ def pathconv_level(p, prefix, csr, h, cell_feat, net_feat, cur_nodes, targets, l
             rows = mlp(p, prefix + 'fc_net_self.', net_feat[idx]) + a                   # :103-109
         elif level_id == 0:
             rows = mlp(p, prefix + 'fc_cell_self.', cell_feat[idx])                     # :148-153
+        elif key is not None:
+            a = seg_attn_sum(h, key, *csr['cell'], cur_nodes, p[prefix + 'fc_key.weight'],
+                             p[prefix + 'fc_attn.weight'])                              # :119-136,190-196
+            rows = mlp(p, prefix + 'fc_cell_self.', cell_feat[idx]) + \
+                mlp(p, prefix + 'fc_cell_neigh.', a)
         else:
             a = seg_softmax_sum(h, *csr['cell'], cur_nodes)                             # :113-116
             rows = mlp(p, prefix + 'fc_cell_self.', cell_feat[idx]) + \
@@ -105,6 +136,12 @@ def pathconv_level(p, prefix, csr, h, cell_feat, net_feat, cur_nodes, targets, l
         h = h.index_copy(0, idx, rows)
     tix = torch.as_tensor(np.asarray(targets, dtype=np.int64))
     return h, h[tix]                                                                    # :213
+
+
+def pathconv_h_drive(csr, net_feat, cur_nodes):
+    """ndata['h_drive'] rows of an even level in the attention branch: fn.copy_src('net_feat') + fn.mean over the NET
+    in-edges, passed through apply_netdrive_func unchanged (src/model.py:197-198,66-86)."""
+    return seg_mean(net_feat, *csr['net'], cur_nodes)
 
 
 # --------------------------------------------------------------------------- PathModel.forward

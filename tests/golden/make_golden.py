@@ -97,6 +97,8 @@ class FakeHeteroGraph:
             return
         indptr, indices = self.csr[etype]
         start, deg = indptr[v], indptr[v + 1] - indptr[v]
+        if not isinstance(message_func, tuple):
+            return self._pull_udf_message(v, start, deg, indices, message_func, reduce_func, apply_node_func)
         assert message_func[0] == 'copy_src'
         src_field, msg_name = message_func[1], message_func[2]
         feat = self.ndata[src_field]
@@ -140,6 +142,49 @@ class FakeHeteroGraph:
             if k not in self.ndata:
                 self.ndata[k] = t.new_zeros((self.n,) + tuple(t.shape[1:]))
             self.ndata[k] = self.ndata[k].index_copy(0, vt, t)
+
+
+    def _pull_udf_message(self, v, start, deg, indices, message_func, reduce_func, apply_node_func):
+        """pull with a message UDF (the attention branch, src/model.py:195-196): the UDF sees an edge batch with
+        .src / .dst node data of the in-edges of `v`, its outputs form the mailbox (n_bucket, deg, ...) per degree
+        bucket; a builtin reducer on one of those messages (fn.max at level 0) leaves zero rows for zero in-degree."""
+        red = {}
+        for d in np.unique(deg):
+            if d == 0:
+                continue
+            sel = np.nonzero(deg == d)[0]
+            eid = (start[sel][:, None] + np.arange(d)[None, :]).reshape(-1)
+            src = torch.from_numpy(indices[eid])
+            dst = torch.from_numpy(np.repeat(v[sel], d))
+
+            class _Edges:
+                pass
+            eb = _Edges()
+            eb.src = {k: t[src] for k, t in self.ndata.items()}
+            eb.dst = {k: t[dst] for k, t in self.ndata.items()}
+            msgs = message_func(eb)
+            mailbox = {k: t.reshape((len(sel), d) + tuple(t.shape[1:])) for k, t in msgs.items()}
+            if isinstance(reduce_func, tuple):
+                kind, mname, out_name = reduce_func
+                r = {out_name: mailbox[mname].mean(1) if kind == 'mean' else mailbox[mname].max(1)[0]}
+            else:
+                r = reduce_func(_Batch(mailbox=mailbox))
+            for k, t in r.items():
+                if k not in red:
+                    red[k] = t.new_zeros((len(v),) + tuple(t.shape[1:]))
+                red[k] = red[k].index_copy(0, torch.from_numpy(sel), t)
+        if isinstance(reduce_func, tuple) and reduce_func[2] not in red:          # no in-edge at all: zero fill
+            ref = self.ndata['h']
+            red[reduce_func[2]] = ref.new_zeros((len(v), ref.shape[1]))
+        vt = torch.from_numpy(v)
+        data = {k: t[vt] for k, t in self.ndata.items()}
+        data.update(red)
+        new = apply_node_func(_Batch(data=data)) if apply_node_func is not None else {}
+        for src_dict in (red, new):
+            for k, t in src_dict.items():
+                if k not in self.ndata:
+                    self.ndata[k] = t.new_zeros((self.n,) + tuple(t.shape[1:]))
+                self.ndata[k] = self.ndata[k].index_copy(0, vt, t)
 
 
 # ----------------------------------------------------------------------------- helpers
@@ -390,6 +435,93 @@ def golden_sweep(ref_model):
     save('pathmodel_variants', **variants)
 
 
+def golden_attention(ref_model):
+    """flag_attn=True (src/model.py:56-58,119-136,190-198).  No reference file creates ndata['key'], so the
+    key is synthetic here - exactly as cell_msg_reduce was pinned on synthetic mailboxes: the reference's own
+    message_func_attn / cell_msg_reduce_attn / apply_netdrive_func run unmodified, first on their own over degree
+    buckets, then inside the unmodified PathConv.forward on the 64-node DAG."""
+    d = _small_design()
+    csr = R.design_csr(d)
+    D = 16
+    # (a) the UDF pair on random edge batches, degrees 1..6
+    conv = ref_model.PathConv(D, D, 36, 2, flag_attn=True)
+    sd = det_state_dict(conv, 71)
+    conv.load_state_dict(sd)
+    outs = {}
+    for deg in range(1, 7):
+        n = 5
+
+        class _E:
+            pass
+        eb = _E()
+        eb.src = {'key': torch.from_numpy(det_uniform((n * deg, 1), 700 + deg, -2.0, 2.0)),
+                  'h': torch.from_numpy(det_uniform((n * deg, D), 710 + deg, -1.0, 3.0))}
+        eb.dst = {'key': torch.from_numpy(np.repeat(det_uniform((n, 1), 720 + deg, -2.0, 2.0), deg, axis=0))}
+        msgs = conv.message_func_attn(eb)
+        mailbox = {k: t.reshape((n, deg) + tuple(t.shape[1:])) for k, t in msgs.items()}
+        r = conv.cell_msg_reduce_attn(_Batch(mailbox=mailbox))['h_neigh1']
+        outs[f'deg{deg}'] = r
+        outs[f'e{deg}'] = msgs['e']
+        # restatement on the equivalent graph: nodes 0..n-1 are the destinations, n.. the sources
+        key = torch.cat([eb.dst['key'][::deg], eb.src['key']], 0)
+        h = torch.cat([torch.zeros(n, D), eb.src['h']], 0)
+        indptr = np.concatenate([np.arange(0, n * deg + 1, deg), np.full(n * deg, n * deg)]).astype(np.int64)
+        indices = (np.arange(n * deg) + n).astype(np.int64)
+        ro = R.seg_attn_sum(h, key, indptr, indices, np.arange(n), sd['fc_key.weight'], sd['fc_attn.weight'])
+        check(f'attention UDFs deg{deg}', ro, r, 2e-6)
+    save('attn_reduce', seed=71, **outs)
+
+    # (b) the whole level loop through the unmodified PathConv.forward
+    for dtype, tol in ((torch.float32, 1e-5), (torch.float64, 1e-11)):
+        gnn = ref_model.PathConv(D, D, 36, 2, flag_attn=True).to(dtype)
+        sd = det_state_dict(gnn, 72)
+        gnn.load_state_dict({k: v.to(dtype) for k, v in sd.items()})
+        key = torch.from_numpy(det_uniform((d.N, 1), 73, -2.0, 2.0)).to(dtype)
+        g = FakeHeteroGraph(d.N, csr)
+        g.ndata['h'] = torch.zeros((d.N, D), dtype=dtype)
+        g.ndata['cell_feat'] = torch.from_numpy(d.cell_feat).to(dtype)
+        g.ndata['net_feat'] = torch.from_numpy(d.net_feat).to(dtype)
+        g.ndata['key'] = key
+        targets_all, outs_l = [], []
+        for level_id, (nodes, targets, _p) in enumerate(d.topo_levels()):
+            t = list(targets) + list(targets[:1])                    # one duplicated target per level
+            targets_all.extend(t)
+            outs_l.append(gnn(g, nodes, None, t, level_id))
+        out = torch.cat(outs_l, 0)
+        wts = torch.from_numpy(det_uniform(tuple(out.shape), 74)).to(dtype)
+        (out * wts).sum().backward()
+        grads = {k: (prm.grad.clone() if prm.grad is not None else None) for k, prm in gnn.named_parameters()}
+        assert grads['fc_key.weight'] is not None and grads['fc_attn.weight'] is not None
+        assert grads['fc_net_drive.layers.0.weight'] is None and grads['fc_attn2.weight'] is None
+        # restatement
+        p = {'gnn.' + k: v.to(dtype).clone().requires_grad_(True) for k, v in sd.items()}
+        h = torch.zeros((d.N, D), dtype=dtype)
+        hd = torch.zeros((d.N, 2), dtype=dtype)
+        ol = []
+        for level_id, (nodes, targets, _p) in enumerate(d.topo_levels()):
+            t = list(targets) + list(targets[:1])
+            h, y = R.pathconv_level(p, 'gnn.', csr, h, g.ndata['cell_feat'], g.ndata['net_feat'], nodes, t, level_id,
+                                    key=key)
+            if level_id % 2 == 0:
+                hd = hd.index_copy(0, torch.as_tensor(nodes), R.pathconv_h_drive(csr, g.ndata['net_feat'], nodes))
+            ol.append(y)
+        oo = torch.cat(ol, 0)
+        (oo * wts).sum().backward()
+        check(f'attention sweep out {dtype}', oo, out, tol)
+        check('attention sweep h', h, g.ndata['h'], tol)
+        check('attention h_drive', hd, g.ndata['h_drive'], tol) if float(g.ndata['h_drive'].abs().max()) > 0 else None
+        assert float((hd - g.ndata['h_drive']).abs().max()) <= tol
+        for k, gr in grads.items():
+            if gr is None:
+                assert p['gnn.' + k].grad is None, k
+            else:
+                check('attention grad ' + k, p['gnn.' + k].grad, gr, tol * 20)
+        if dtype == torch.float32:
+            save('sweep_attn', seed=72, key_seed=73, wts_seed=74, out=out, h_final=g.ndata['h'],
+                 h_drive=g.ndata['h_drive'], targets=np.array(targets_all),
+                 **{'g_' + k.replace('.', '_'): v for k, v in grads.items() if v is not None})
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -400,6 +532,7 @@ def main():
     golden_layoutnet(ref_model)
     golden_unet(ref_unet)
     golden_sweep(ref_model)
+    golden_attention(ref_model)
     print('all fixtures written; oracle restatement agrees with the reference on every one of them')
 
 
