@@ -390,6 +390,72 @@ def pair_fwd_gather(h, pre, in_net, in_cell, net_range, cell_rows, A, LSE, relu=
              heavy.numel() if heavy is not None else 0, int(heavy_thresh), int(alg_bytes), dev, st)
 
 
+ATTN_SLOPE = 0.01          # F.leaky_relu default (src/model.py:136)
+
+
+def seg_attn_fwd(h, key, c12, in_csr, rows, A, alpha):
+    """Attention aggregation of one cell level (mmft_seg_attn_fwd): A[v] = sum_i softmax_i(e_i) h[u_i]."""
+    _rows2d(h, 'h'); _rows2d(A, 'A'); _chk(key, 'key'); _chk(c12, 'c12'); _chk(alpha, 'alpha')
+    N = h.shape[0]
+    _csr(in_csr[0], in_csr[1], N, 'in_csr')
+    if key.numel() != N or not key.is_contiguous() or c12.numel() != 2 or not c12.is_contiguous():
+        raise ValueError("seg_attn_fwd: key must hold one value per node, c12 two scalars")
+    if alpha.numel() != in_csr[1].numel() or not alpha.is_contiguous() or A.shape != h.shape:
+        raise ValueError('seg_attn_fwd: alpha needs one slot per in-edge, A the layout of h')
+    rt, row0, n = _rowspec(rows, N, 'rows')
+    dev, st = lib.stream_args(h)
+    lib.call('mmft_seg_attn_fwd', h, h.stride(0), key, c12, ATTN_SLOPE, in_csr[0], in_csr[1], rt, row0, n, h.shape[1], A,
+             A.stride(0), alpha, dev, st)
+    return A
+
+
+def level_bwd_pull_attn(G, h, rows, out_net, out_net_w, out_cell, o2i, alpha, DA, relu=True, own=None):
+    for t, nm in ((G, 'G'), (h, 'h'), (DA, 'DA')):
+        _rows2d(t, nm)
+        if t.shape != h.shape or t.stride(0) != h.stride(0):
+            raise ValueError(f'level_bwd_pull_attn: {nm} must have the layout of h')
+    N = h.shape[0]
+    _csr(out_net[0], out_net[1], N, 'out_net'); _csr(out_cell[0], out_cell[1], N, 'out_cell')
+    _idx(o2i, 'o2i', out_cell[1].numel()); _chk(alpha, 'alpha'); _chk(out_net_w, 'out_net_w')
+    if alpha.numel() != out_cell[1].numel() or out_net_w.numel() != out_net[1].numel():
+        raise ValueError('level_bwd_pull_attn: one alpha per cell edge, one weight per net edge expected')
+    rt, row0, n = _rowspec(rows, N, 'rows')
+    if own is not None:
+        _chk(own, 'own', torch.uint8)
+    dev, st = lib.stream_args(h)
+    lib.call('mmft_level_bwd_pull_attn', G, h, h.stride(0), rt, row0, n, h.shape[1], out_net[0], out_net[1], out_net_w,
+             out_cell[0], out_cell[1], o2i, alpha, DA, int(relu), own, dev, st)
+    return G
+
+
+def seg_attn_bwd_scores(DA, h, A, alpha, key, c12, in_csr, rows, dcp):
+    for t, nm in ((DA, 'DA'), (h, 'h'), (A, 'A')):
+        _rows2d(t, nm)
+        if t.shape != h.shape or t.stride(0) != h.stride(0):
+            raise ValueError(f'seg_attn_bwd_scores: {nm} must have the layout of h')
+    N = h.shape[0]
+    _csr(in_csr[0], in_csr[1], N, 'in_csr'); _chk(dcp, 'dcp')
+    if tuple(dcp.shape) != (N, 2) or not dcp.is_contiguous():
+        raise ValueError('seg_attn_bwd_scores: dcp must be a contiguous [N, 2] tensor')
+    rt, row0, n = _rowspec(rows, N, 'rows')
+    dev, st = lib.stream_args(h)
+    lib.call('mmft_seg_attn_bwd_scores', DA, h, A, h.stride(0), alpha, key, c12, ATTN_SLOPE, in_csr[0], in_csr[1], rt, row0, n,
+             h.shape[1], dcp, dev, st)
+    return dcp
+
+
+def seg_mean_rows_any(src, csr, rows, out):
+    """out[rows] = mean over the CSR segments of rows of src (any width; scatter by node id)."""
+    _rows2d(src, 'src'); _rows2d(out, 'out'); _idx(rows, 'rows')
+    _csr(csr[0], csr[1], src.shape[0], 'csr')
+    if out.shape[1] != src.shape[1] or out.shape[0] != src.shape[0]:
+        raise ValueError('seg_mean_rows_any: out must have the shape of src')
+    dev, st = lib.stream_args(src)
+    lib.call('mmft_seg_mean_rows_any', src, src.stride(0), csr[0], csr[1], rows, rows.numel(), src.shape[1], out,
+             out.stride(0), 1, dev, st)
+    return out
+
+
 def gather_rows(src, idx):
     _rows2d(src, 'src'); _idx(idx, 'idx')
     out = torch.empty((idx.numel(), src.shape[1]), dtype=torch.float32, device=src.device)

@@ -148,6 +148,18 @@ class PinGraph:
             self._csr_dev['onw'] = torch.from_numpy((1.0 / np.maximum(indeg, 1)).astype(np.float32)).to(self.device)
         return self._csr_dev['onw']
 
+    def out2in(self, etype):
+        """int32[E] on the device: out-CSR edge position -> in-CSR position of the same edge (per-edge data such as the
+        attention weights is stored in in-CSR order, the reverse sweep walks out-edges)."""
+        key = ('o2i', etype)
+        if key not in self._csr_dev:
+            perm_in = self._csr_host[('in', etype)][2]
+            perm_out = self._csr_host[('out', etype)][2]
+            inv_in = np.empty_like(perm_in)
+            inv_in[perm_in] = np.arange(perm_in.shape[0])
+            self._csr_dev[key] = torch.from_numpy(inv_in[perm_out].astype(np.int32)).to(self.device)
+        return self._csr_dev[key]
+
     def csr_host(self, direction, etype):
         ip, idx, _ = self._csr_host[(direction, etype)]
         return ip, idx

@@ -58,6 +58,7 @@ class SweepState:
         self.complete = False               # level lists = a complete schedule of the graph (whole-sweep entry)
         self.fold = None                    # static facts for the folded level kernels (PinGraph.fold_schedule)
         self.PRE = None
+        self.attn = None                    # attention branch (flag_attn): dict(key, c12, alpha, dcp, o2i)
         self.target_order = None
         self.targets_unique = None
 
@@ -90,6 +91,57 @@ class SweepState:
             if zero_da:
                 self.DA.zero_()
             self.bwd_active = True
+
+
+def _attn_state(st, graph, c12):
+    """Buffers of the attention branch (src/model.py:119-136,190-196): ndata['key'] as a flat vector, the two score
+    coefficients on the device, alpha per cell in-edge, per-node score-gradient partials."""
+    key = graph.ndata.get('key')
+    if key is None:
+        raise RuntimeError("PathConv(flag_attn=True) reads graph.ndata['key'] (src/model.py:132-136); no reference file "
+                           "creates it (SURVEY D6) - provide a float32 [N, 1] tensor")
+    if not (torch.is_tensor(key) and key.is_cuda and key.dtype == torch.float32 and key.numel() == st.N):
+        raise RuntimeError("graph.ndata['key'] must be a float32 CUDA tensor with one value per node")
+    E = graph.csr('in', 'cell')[1].numel()
+    bufs = st._bufs
+    if bufs.get('alpha') is None or bufs['alpha'].numel() != max(E, 1):
+        bufs['alpha'] = torch.zeros(max(E, 1), dtype=torch.float32, device=st.h.device)
+        bufs['dcp'] = torch.zeros((st.N, 2), dtype=torch.float32, device=st.h.device)
+    return dict(key=key.reshape(-1).contiguous(), c12=c12.detach().reshape(2).contiguous(), alpha=bufs['alpha'],
+                dcp=bufs['dcp'], o2i=graph.out2in('cell'))
+
+
+def _cell_gather_fwd(st, g, rows):
+    """A[rows] (and what the reverse sweep needs) for one cell level: per-channel softmax (src/model.py:113-116) or,
+    with flag_attn, one softmax weight per edge (src/model.py:119-136)."""
+    if st.attn is not None:
+        a = st.attn
+        ops.seg_attn_fwd(st.h, a['key'], a['c12'], g.csr('in', 'cell'), rows, st.A, a['alpha'])
+    else:
+        ops.seg_softmax_sum_fwd(st.h, g.csr('in', 'cell'), rows, st.A, st.LSE)
+
+
+def _pull_bwd(st, g, rows, own=None, alg_bytes=0, heavy=None):
+    if st.attn is not None:
+        a = st.attn
+        ops.level_bwd_pull_attn(st.G, st.h, rows, g.csr('out', 'net'), g.out_net_weight(), g.csr('out', 'cell'), a['o2i'],
+                                a['alpha'], st.DA, relu=st.relu, own=own)
+    else:
+        ops.level_bwd_pull(st.G, st.h, rows, g.csr('out', 'net'), g.out_net_weight(), g.csr('out', 'cell'),
+                           st.A, st.LSE, st.DA, relu=st.relu, alg_bytes=alg_bytes, own=own, heavy=heavy)
+
+
+def _attn_scores_bwd(st, g, rows):
+    a = st.attn
+    ops.seg_attn_bwd_scores(st.DA, st.h, st.A, a['alpha'], a['key'], a['c12'], g.csr('in', 'cell'), rows, a['dcp'])
+
+
+def _attn_c12_grad(st, rows):
+    """d loss / d c12 (2, 1) = the column sums of the score-gradient partials of the cell rows (range or index)."""
+    dcp = st.attn['dcp']
+    if isinstance(rows, tuple):
+        return ops.colsum(dcp[rows[0]:rows[0] + rows[1]]).reshape(2, 1)
+    return ops.colsum(dcp, idx=rows).reshape(2, 1)
 
 
 def _feat(graph, name, width):
@@ -142,11 +194,14 @@ def _cell_neigh_bwd(st, rows, w1g, w2g, keep_dhn=False):
 
 
 class LevelFn(torch.autograd.Function):
-    """One PathConv.forward call. Inputs: chain token (+ the 12 MLP parameters at level 0)."""
+    """One PathConv.forward call. Inputs: chain token, the attention coefficients c12 (or None) (+ the 12 MLP parameters
+    at level 0)."""
 
     @staticmethod
-    def forward(ctx, token, state, level_id, rows, tix, *params):
+    def forward(ctx, token, state, level_id, rows, tix, c12, *params):
         st, g = state, state.graph
+        if c12 is not None:
+            st.attn = _attn_state(st, g, c12)
         P = [_w(p) for p in st.params]
         (w1c, b1c, w2c, b2c, w1n, b1n, w2n, b2n, w1g, b1g, w2g, b2g) = P
         n = rows.numel()
@@ -160,7 +215,7 @@ class LevelFn(torch.autograd.Function):
                 ops.linear_fwd(st.cell_feat, w1c, b1c, y=st.HS, xidx=rows, yidx=rows, act=ops.ACT_RELU)
                 ops.linear_fwd(st.HS, w2c, b2c, y=st.h, xidx=rows, yidx=rows, act=act)
             else:                                                                     # cell level :113-116,138-146
-                ops.seg_softmax_sum_fwd(st.h, g.csr('in', 'cell'), rows, st.A, st.LSE)
+                _cell_gather_fwd(st, g, rows)
                 ops.linear_fwd(st.cell_feat, w1c, b1c, y=st.HS, xidx=rows, yidx=rows, act=ops.ACT_RELU)
                 ops.linear_fwd(st.HS, w2c, b2c, y=st.h, xidx=rows, yidx=rows)
                 _cell_neigh_fwd(st, rows, w1g, b1g, w2g, b2g, act)
@@ -168,6 +223,7 @@ class LevelFn(torch.autograd.Function):
         out = ops.gather_rows(st.h, tix) if tix.numel() else st.h.new_zeros((0, st.D))       # :213
         ctx.state, ctx.level_id, ctx.rows, ctx.tix = st, level_id, rows, tix
         ctx.nparams = len(params)
+        ctx.has_c12 = c12 is not None
         new_token = st.h.new_zeros(1)
         return new_token, out
 
@@ -180,17 +236,20 @@ class LevelFn(torch.autograd.Function):
             ops.scatter_add_targets(st.G, ctx.tix, go, unique=g.__dict__.get('targets_unique'))
         P = [_w(p) for p in st.params]
         (w1c, b1c, w2c, b2c, w1n, b1n, w2n, b2n, w1g, b1g, w2g, b2g) = P
+        dc = None
         if rows.numel():
-            ops.level_bwd_pull(st.G, st.h, rows, g.csr('out', 'net'), g.out_net_weight(), g.csr('out', 'cell'),
-                               st.A, st.LSE, st.DA, relu=st.relu)
+            _pull_bwd(st, g, rows)
             if level_id % 2 == 0 and level_id > 0:
                 _cell_neigh_bwd(st, rows, w1g, w2g)
+                if ctx.has_c12 and st.attn is not None:
+                    _attn_scores_bwd(st, g, rows)
+                    dc = _attn_c12_grad(st, rows)
         grads = [None] * ctx.nparams
         if level_id == 0:
             if ctx.nparams:
                 grads = _batched_param_grads(st, P)
             st.bwd_active = False
-        return (torch.zeros_like(gtoken) if ctx.needs_input_grad[0] else None, None, None, None, None, *grads)
+        return (torch.zeros_like(gtoken) if ctx.needs_input_grad[0] else None, None, None, None, None, dc, *grads)
 
 
 def _cat_rows(st, pred):
@@ -261,8 +320,17 @@ def _batched_param_grads(st, P, dhn_ready=False):
     return gc + gn + gg
 
 
+def attention_coefficients(conv):
+    """c12 (2, 1): <fc_attn.w[:dk], fc_key.w> and <fc_attn.w[dk:], fc_key.w> - the edge score of message_func_attn
+    (src/model.py:132-136) is leaky_relu(c12[0] key_src + c12[1] key_dst) because fc_key / fc_attn have no bias.  One tiny
+    GEMM through the autograd-aware dense kernel, so the gradient reaches both parameters."""
+    from . import functional as MF
+    dk = conv.fc_key.weight.shape[0]
+    return MF.linear_act(conv.fc_attn.weight.view(2, dk), conv.fc_key.weight.view(1, dk), None, None)
+
+
 def level_forward(conv, graph, cur_nodes, targets, level_id):
-    """Body of PathConv.forward for the default (non-attention) branch."""
+    """Body of PathConv.forward (both branches)."""
     if level_id == 0 or graph._sweep is None:
         if level_id != 0:
             raise RuntimeError('PathConv: a sweep must start at level 0 (src/train.py:489-490)')
@@ -275,19 +343,30 @@ def level_forward(conv, graph, cur_nodes, targets, level_id):
     st.next_level = level_id + 1
     rows = graph.level_rows(level_id, cur_nodes, 'nodes')
     tix = graph.level_rows(level_id, targets, 'targets')
+    c12 = None
+    if getattr(conv, 'flag_attn', False) and level_id % 2 == 0:
+        if level_id > 0:
+            c12 = attention_coefficients(conv)                                           # src/model.py:132-136
+        # second pull of the branch: ndata['h_drive'] = mean of net_feat over the NET in-edges (src/model.py:197-198)
+        hd = graph.ndata.get('h_drive')
+        if hd is None or hd.shape != st.net_feat.shape or hd.device != st.net_feat.device:
+            hd = torch.zeros_like(st.net_feat)
+            graph.ndata['h_drive'] = hd
+        if rows.numel():
+            ops.seg_mean_rows_any(st.net_feat, graph.csr('in', 'net'), rows, hd)
     if level_id == 0:
         token = st.h.new_zeros(1)
         if st.need_grad:
-            st.token, out = LevelFn.apply(token, st, level_id, rows, tix, *st.params)
+            st.token, out = LevelFn.apply(token, st, level_id, rows, tix, c12, *st.params)
         else:
             with torch.no_grad():
-                st.token, out = LevelFn.apply(token, st, level_id, rows, tix)
+                st.token, out = LevelFn.apply(token, st, level_id, rows, tix, c12)
     else:
         if st.need_grad:
-            st.token, out = LevelFn.apply(st.token, st, level_id, rows, tix)
+            st.token, out = LevelFn.apply(st.token, st, level_id, rows, tix, c12)
         else:
             with torch.no_grad():
-                st.token, out = LevelFn.apply(st.token, st, level_id, rows, tix)
+                st.token, out = LevelFn.apply(st.token, st, level_id, rows, tix, c12)
     return out
 
 
@@ -336,8 +415,9 @@ def check_persistent_error(graph):
 
 class SweepFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, state, level_rows, tix, *params):
+    def forward(ctx, state, level_rows, tix, c12, *params):
         st, g = state, state.graph
+        st.attn = _attn_state(st, g, c12) if c12 is not None else None
         P = [_w(p) for p in st.params]
         (w1c, b1c, w2c, b2c, w1n, b1n, w2n, b2n, w1g, b1g, w2g, b2g) = P
         act = ops.ACT_RELU if st.relu else ops.ACT_NONE
@@ -353,14 +433,14 @@ class SweepFn(torch.autograd.Function):
         if rc2 is not None:                                                              # fc_cell_self, all cell nodes
             _linear_rows(st.cell_feat, w1c, b1c, st.HS, rc2, act=ops.ACT_RELU)
             _linear_rows(st.HS, w2c, b2c, st.h, rc2)
-        fold = st.fold if (FOLD_LEVELS and not PERSISTENT_FORWARD) else None
+        fold = st.fold if (FOLD_LEVELS and not PERSISTENT_FORWARD and st.attn is None) else None
         if fold is not None:
             st.PRE = st._buf('PRE', st.D)     # fc_net_self outputs live apart from h: the folded gather updates h in place
         if rn is not None:                                                               # fc_net_self, all net nodes
             _linear_rows(st.net_feat, w1n, b1n, st.HS, rn, act=ops.ACT_RELU)
             _linear_rows(st.HS, w2n, b2n, st.PRE if fold is not None else st.h, rn)
         in_net, in_cell = g.csr('in', 'net'), g.csr('in', 'cell')
-        persistent = PERSISTENT_FORWARD and ops.mlp2_fusable(st.D, st.Hd, st.D) and len(level_rows) > 1
+        persistent = PERSISTENT_FORWARD and ops.mlp2_fusable(st.D, st.Hd, st.D) and len(level_rows) > 1 and st.attn is None
         if persistent:
             check_persistent_error(g)
             ps = _persist_state(g, level_rows)
@@ -392,10 +472,14 @@ class SweepFn(torch.autograd.Function):
             spec = meta['range'] if (meta and meta['range']) else rows       # contiguous levels: no index array
             if level_id % 2 == 1:
                 ops.seg_mean_add_act_fwd(st.h, in_net, spec, relu=st.relu, alg_bytes=meta['bytes_mean'] if meta else 0)
+            elif st.attn is not None:
+                _cell_gather_fwd(st, g, spec)
+                _cell_neigh_fwd(st, rows, w1g, b1g, w2g, b2g, act)
             else:
                 ops.seg_softmax_sum_fwd(st.h, in_cell, spec, st.A, st.LSE, alg_bytes=meta['bytes_softmax'] if meta else 0)
                 _cell_neigh_fwd(st, rows, w1g, b1g, w2g, b2g, act)
         ctx.state, ctx.tix, ctx.nparams = st, tix, len(params)
+        ctx.has_c12 = c12 is not None
         return ops.gather_rows(st.h, tix) if tix.numel() else st.h.new_zeros((0, st.D))
 
     @staticmethod
@@ -422,16 +506,21 @@ class SweepFn(torch.autograd.Function):
                 continue
             meta = st.level_meta[level_id] if st.level_meta else None
             spec = meta['range'] if (meta and meta['range']) else rows
-            ops.level_bwd_pull(st.G, st.h, spec, out_net, in_net_ptr, out_cell, st.A, st.LSE, st.DA, relu=st.relu,
-                               alg_bytes=meta['bytes_pull'] if meta else 0, own=own,
-                               heavy=meta['heavy_out'] if meta else None)
+            _pull_bwd(st, g, spec, own=own, alg_bytes=meta['bytes_pull'] if meta else 0,
+                      heavy=meta['heavy_out'] if meta else None)
             if level_id % 2 == 0 and level_id > 0:
                 _cell_neigh_bwd(st, rows, w1g, w2g, keep_dhn=True)
+                if ctx.has_c12:
+                    _attn_scores_bwd(st, g, spec)
         grads = _batched_param_grads(st, P, dhn_ready=True) if ctx.nparams else []
+        dc = None
+        if ctx.has_c12:
+            rc2 = st.row_sets[2]
+            dc = _attn_c12_grad(st, rc2) if rc2 is not None else torch.zeros((2, 1), dtype=torch.float32, device=st.h.device)
         if ctx.tix.numel() and fast:
             ops.target_rows_end(ctx.tix, st.tflag)
         st.bwd_active = False
-        return (None, None, None, *grads)
+        return (None, None, None, dc, *grads)
 
 
 def sweep_forward_all(conv, graph, level_nodes, targets, target_order=None, targets_unique=None):
@@ -442,14 +531,22 @@ def sweep_forward_all(conv, graph, level_nodes, targets, target_order=None, targ
     st = SweepState(graph, conv)
     graph._sweep = st
     st.complete = graph.level_set_is_complete(level_nodes)
-    st.fold = graph.fold_schedule(level_nodes) if (FOLD_LEVELS and st.complete) else None
+    st.fold = graph.fold_schedule(level_nodes) if (FOLD_LEVELS and st.complete and not getattr(conv, 'flag_attn', False)) else None
     st.target_order, st.targets_unique = target_order, targets_unique
     level_rows = [graph.level_rows(l, nodes, 'nodes') for l, nodes in enumerate(level_nodes)]
     st.level_meta = [graph.level_meta(l, nodes, st.D) if not torch.is_tensor(nodes) else None
                      for l, nodes in enumerate(level_nodes)]
     tix = graph.level_rows(-1, targets, 'sweep_targets')
     st.next_level = len(level_rows)
-    if st.need_grad:
-        return SweepFn.apply(st, level_rows, tix, *st.params)
+    c12 = None
+    if getattr(conv, 'flag_attn', False):
+        c12 = attention_coefficients(conv)
+        hd = torch.zeros_like(st.net_feat)                     # ndata['h_drive'] of the even levels (src/model.py:197-198)
+        for l in range(0, len(level_rows), 2):
+            if level_rows[l].numel():
+                ops.seg_mean_rows_any(st.net_feat, graph.csr('in', 'net'), level_rows[l], hd)
+        graph.ndata['h_drive'] = hd
+    if st.need_grad or (c12 is not None and c12.requires_grad):
+        return SweepFn.apply(st, level_rows, tix, c12, *st.params)
     with torch.no_grad():
-        return SweepFn.apply(st, level_rows, tix)
+        return SweepFn.apply(st, level_rows, tix, c12)

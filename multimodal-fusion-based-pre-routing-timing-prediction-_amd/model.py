@@ -81,10 +81,10 @@ class PathConv(nn.Module):
         self.norm = norm
 
     def forward(self, graph, cur_nodes, eids, targets, level_id):
-        """Returns h[targets] of shape (len(targets), out_feat_dim); `eids` is ignored."""
-        if self.flag_attn:
-            raise NotImplementedError("flag_attn=True reads ndata['key'], which no reference file creates "
-                                      "(src/model.py:132-136): not runnable on reference data, parity unpinned")
+        """Returns h[targets] of shape (len(targets), out_feat_dim); `eids` is ignored.
+        flag_attn=True (src/model.py:190-198) reads graph.ndata['key'] (N, 1), which no reference file creates
+        (SURVEY D6): the caller has to provide it; the branch is pinned against the reference's own UDFs on a synthetic
+        key (tests/golden/attn_reduce.npz, sweep_attn.npz)."""
         return _sweep.level_forward(self, graph, cur_nodes, targets, level_id)
 
 

@@ -203,6 +203,45 @@ def test_sweep_golden(dev, sparse):
             assert prm.grad is None, f'{k} should not receive a gradient (unused in forward)'
 
 
+@pytest.mark.parametrize('entry', ['dropin', 'sweep'])
+def test_attention_branch_golden(dev, entry):
+    """PathConv(flag_attn=True) (src/model.py:56-58,119-136,190-198) against what the reference's unmodified
+    PathConv.forward produced on the fixture DAG with a synthetic ndata['key'] (tests/golden/sweep_attn.npz): outputs,
+    final embeddings, ndata['h_drive'] and every parameter gradient incl. fc_key / fc_attn; per-level drop-in calls and
+    the whole-sweep entry."""
+    import model
+    from test_oracle_golden import attn_level_targets
+    from mmft import sweep as S
+    g, gd = gold('sweep_attn'), gold('sweep_small')
+    d = _fixture_design(gd)
+    D = 16
+    gnn = load_det(model.PathConv(D, D, 36, 2, flag_attn=True), 72, dev)
+    graph = PinGraph(d.N, {'net': (d.net_src, d.net_dst), 'cell': (d.cell_src, d.cell_dst)})
+    graph.ndata['cell_feat'] = torch.from_numpy(d.cell_feat)
+    graph.ndata['net_feat'] = torch.from_numpy(d.net_feat)
+    graph.ndata['key'] = torch.from_numpy(det_uniform((d.N, 1), 73, -2.0, 2.0))
+    graph.ndata['h'] = torch.zeros((d.N, D))
+    graph = graph.to(dev)
+    targets = attn_level_targets(gd)
+    if entry == 'dropin':
+        out = torch.cat([gnn(graph, [int(v) for v in d.levels[l]], None, targets[l], l) for l in range(d.L)], 0)
+    else:
+        # the whole-sweep entry returns the targets in one gather after the last level (rows are final once written)
+        flat = torch.tensor([t for tl in targets for t in tl], dtype=torch.int32, device=dev)
+        out = S.sweep_forward_all(gnn, graph, [[int(v) for v in lv] for lv in d.levels], flat)
+    wts = torch.from_numpy(det_uniform(tuple(out.shape), 74)).to(dev)
+    (out * wts).sum().backward()
+    close(out, g['out'], what='out')
+    close(graph.ndata['h'], g['h_final'], what='h')
+    assert float((graph.ndata['h_drive'].cpu() - torch.from_numpy(g['h_drive'])).abs().max()) < 1e-6
+    for k, prm in gnn.named_parameters():
+        key = 'g_' + k.replace('.', '_')
+        if key in g.files:
+            close(prm.grad, g[key], 3e-4, key)
+        else:
+            assert prm.grad is None, f'{k} should not receive a gradient (unused in forward)'
+
+
 def test_pathmodel_variants_golden(dev):
     import model
     g = gold('pathmodel_variants')

@@ -169,3 +169,79 @@ def test_sweep_small():
     close(p['gnn.fc_cell_neigh.layers.0.weight'].grad, g['g_gnn_fc_cell_neigh_layers_0_weight'], 1e-4)
     close(p['fcn.weight'].grad, g['g_fcn_weight'], 1e-4)
     assert p['gnn.fc_net_drive.layers.0.weight'].grad is None and p['gnn.fc_attn2.weight'].grad is None
+
+
+# ------------------------------------------------------------------------------------------------ attention branch
+def _attn_shapes(D):
+    shapes = {}
+    for name, (i, hd, o) in {'fc_cell_neigh': (D, 256, D), 'fc_cell_self': (36, 256, D), 'fc_net_self': (2, 256, D)}.items():
+        shapes[name + '.layers.0.weight'], shapes[name + '.layers.0.bias'] = (hd, i), (hd,)
+        shapes[name + '.layers.2.weight'], shapes[name + '.layers.2.bias'] = (o, hd), (o,)
+    shapes['fc_net_drive.layers.0.weight'], shapes['fc_net_drive.layers.0.bias'] = (D, 2), (D,)
+    shapes['fc_attn2.weight'] = (1, D)
+    shapes['fc_key.weight'], shapes['fc_attn.weight'] = (256, 1), (1, 512)
+    return shapes
+
+
+def attn_level_targets(g):
+    """Per-level target lists of the sweep_attn fixture: the level's endpoints in path order + the first one again."""
+    p2l, p2e = g['path2level'], g['path2endpoint']
+    out = []
+    for l in range(len(g['level_sizes'])):
+        t = [int(p2e[p]) for p in range(len(p2l)) if int(p2l[p]) == l]
+        out.append(t + t[:1])
+    return out
+
+
+def test_attention_udfs():
+    """message_func_attn + cell_msg_reduce_attn (src/model.py:125-136) on the edge batches the reference's own UDFs ran on."""
+    g = gold('attn_reduce')
+    D, n = 16, 5
+    sd = det_state_dict(_Shape(_attn_shapes(D)), 71)
+    for deg in range(1, 7):
+        ksrc = torch.from_numpy(det_uniform((n * deg, 1), 700 + deg, -2.0, 2.0))
+        hsrc = torch.from_numpy(det_uniform((n * deg, D), 710 + deg, -1.0, 3.0))
+        kdst = torch.from_numpy(det_uniform((n, 1), 720 + deg, -2.0, 2.0))
+        key = torch.cat([kdst, ksrc], 0)
+        h = torch.cat([torch.zeros(n, D), hsrc], 0)
+        indptr = np.concatenate([np.arange(0, n * deg + 1, deg), np.full(n * deg, n * deg)]).astype(np.int64)
+        out = R.seg_attn_sum(h, key, indptr, (np.arange(n * deg) + n).astype(np.int64), np.arange(n), sd['fc_key.weight'],
+                             sd['fc_attn.weight'])
+        close(out, g[f'deg{deg}'], 2e-6, f'deg{deg}')
+
+
+def test_sweep_attention():
+    """The whole level loop with flag_attn=True on the fixture DAG: restatement vs the reference's unmodified
+    PathConv.forward (synthetic ndata['key'])."""
+    g, gd = gold('sweep_attn'), gold('sweep_small')
+    N, D = int(gd['cell_feat'].shape[0]), 16
+    sizes = gd['level_sizes']
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    levels = [gd['level_nodes'][starts[i]:starts[i + 1]] for i in range(len(sizes))]
+
+    class Dz:
+        pass
+    d = Dz()
+    d.N, d.net_src, d.net_dst, d.cell_src, d.cell_dst = N, gd['net_src'], gd['net_dst'], gd['cell_src'], gd['cell_dst']
+    csr = R.design_csr(d)
+    p = {'gnn.' + k: v.requires_grad_(True) for k, v in det_state_dict(_Shape(_attn_shapes(D)), 72).items()}
+    key = torch.from_numpy(det_uniform((N, 1), 73, -2.0, 2.0))
+    cf, nf = torch.from_numpy(gd['cell_feat']), torch.from_numpy(gd['net_feat'])
+    h, outs, tl = torch.zeros((N, D)), [], []
+    hd = torch.zeros((N, 2))
+    for level_id, t in enumerate(attn_level_targets(gd)):
+        tl.extend(t)
+        h, y = R.pathconv_level(p, 'gnn.', csr, h, cf, nf, levels[level_id], t, level_id, key=key)
+        if level_id % 2 == 0:
+            hd = hd.index_copy(0, torch.as_tensor(levels[level_id]), R.pathconv_h_drive(csr, nf, levels[level_id]))
+        outs.append(y)
+    out = torch.cat(outs, 0)
+    assert tl == [int(v) for v in g['targets']]
+    wts = torch.from_numpy(det_uniform(tuple(out.shape), 74))
+    (out * wts).sum().backward()
+    close(out, g['out'], 1e-5, 'out')
+    close(h, g['h_final'], 1e-5, 'h')
+    assert float((hd - torch.from_numpy(g['h_drive'])).abs().max()) < 1e-6
+    for k in ('fc_key.weight', 'fc_attn.weight', 'fc_cell_neigh.layers.0.weight', 'fc_net_self.layers.2.bias'):
+        close(p['gnn.' + k].grad, g['g_' + k.replace('.', '_')], 2e-4, k)
+    assert p['gnn.fc_net_drive.layers.0.weight'].grad is None and p['gnn.fc_attn2.weight'].grad is None
