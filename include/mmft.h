@@ -266,6 +266,10 @@ int mmft_bn_train_bwd(const float* gy, const float* x, const float* y, const flo
 int mmft_pool2x2_fwd(const float* x, float* y, int Nimg, int H, int W, int C, int mode, int device, void* stream);
 int mmft_pool2x2_bwd(const float* x, const float* gy, float* dx, int Nimg, int H, int W, int C, int mode,
                      int device, void* stream);
+/* nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) of Up(bilinear=True) (src/Unet.py:48-51): NHWC,
+ * (N,H,W,C) -> (N,2H,2W,C), ATen's source-index arithmetic; the backward is a deterministic gather (no atomics) */
+int mmft_upsample_bilinear2x_fwd(const float* x, float* y, int Nimg, int H, int W, int C, int device, void* stream);
+int mmft_upsample_bilinear2x_bwd(const float* gy, float* dx, int Nimg, int H, int W, int C, int device, void* stream);
 /* ConvTranspose2d(k=2,s=2) = GEMM [pixels x Ci]*[Ci x 4Co] + pixel shuffle (src/Unet.py:53):
  * shuffle:   out[n][2y+a][2x+b][co] = in[n][y][x][(a*2+b)*Co+co] + bias[co]
  * unshuffle: out[n][y][x][(a*2+b)*Co+co] = in[n][2y+a][2x+b][co] */
@@ -332,12 +336,22 @@ int mmft_masked_fc_bwd(const int* csc_indptr, const int* csc_paths, const int* f
 /* loss = mean((pred-target)^2); grad[i] = 2*(pred[i]-target[i])/n   (single workgroup, n <= 2^24) */
 int mmft_mse_fwd_bwd(const float* pred, const float* target, int n, float* loss, float* grad,
                      int device, void* stream);
+/* nn.CrossEntropyLoss() (mean) of the classification task (--task cls, nlabels classes; src/train.py:32,516-518) over
+ * logits [n][C] and int64 labels: loss[0] = mean_t (logsumexp z_t - z_t[y_t]), grad[t][c] = (softmax - onehot) / n (grad may
+ * be NULL).  eval_out (optional fp64[6]) = n, sum of losses, tp, fp, tn, fn with predicted class = argmax (first maximum)
+ * and positive = class != 0 (src/train.py:516,536-541).  Labels must lie in [0, C).  Single workgroup, n <= 2^24. */
+int mmft_cross_entropy_fwd_bwd(const float* logits, const long long* labels, int n, int C, float* loss, float* grad,
+                               double* eval_out, int device, void* stream);
 /* Evaluation sums of validate() / test() (src/train.py:230-278, src/test.py:211-216,231-300) in one pass, fp64:
  * out[0..9] = n, sum y, sum y^2, sum (p-y)^2, sum |p-y|, sum |p-y|/|y| (MAPE numerator, y != 0),
  *             tp, fp, tn, fn   with predicted critical = (required - p) < 0 (judge_critical, src/train.py:391-395)
  *             and actual critical = label != 0.   Single workgroup, n <= 2^24. */
 int mmft_eval_sums(const float* pred, const float* arrival, const float* required, const float* label,
                    int n, double* out, int device, void* stream);
+/* the same ten sums PER TOPOLOGICAL LEVEL: out[l][0..9] over the batch rows with level[i] == l, l < num_levels
+ * (src/test.py:211-216 prints R2 and MAPE of every level) */
+int mmft_eval_sums_by_level(const float* pred, const float* arrival, const float* required, const float* label,
+                            const int* level, int n, int num_levels, double* out, int device, void* stream);
 /* one Adam step over flat buffers, same operation order as torch.optim.Adam (amsgrad=False):
  * g += wd*p; m = lerp(m, g, 1-b1); v = b2*v + (1-b2)*g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
  * gscale multiplies the gradient first (1/world_size after a sum all-reduce) */

@@ -11,7 +11,11 @@ Reference behaviours kept on purpose:
   D3  forward accepts (C,H,W) as well as (N,C,H,W);
   D5  BatchNorm always uses batch statistics (the reference never calls eval()); running stats are
       still updated;
-  D10 one pooling module instance is shared by down1/2/3 and outc.
+  D10 one pooling module instance is shared by down1/2/3 and outc;
+  D12 UNet(pooling, bilinear=True) cannot run in the reference either: up3 then has 16 // 2 = 8 output channels while
+      OutConv is built for 16 (src/Unet.py:103-104,108) - "expected input ... to have 16 channels, but got 8".  The Up
+      module itself works with bilinear=True and is supported here (align_corners=True x2 kernel); the whole UNet with
+      bilinear=True raises the same kind of channel-mismatch error as the reference's.
 `per_sample_stats` (extra, default False) makes BatchNorm take statistics per image, which is what
 batching several designs needs to stay equal to the reference's one-image-at-a-time loop.
 """
@@ -77,9 +81,12 @@ class Up(nn.Module):
 
     def __init__(self, in_channels, out_channels, bilinear=True):
         super().__init__()
+        self.bilinear = bool(bilinear)
         if bilinear:
-            raise NotImplementedError('bilinear=True is never used by the reference (UNet(pooling) defaults to '
-                                      'bilinear=False, src/train.py:70); no HIP kernel')
+            # src/Unet.py:48-51; the module only holds the configuration, forward() goes to the HIP kernel
+            self.up = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+            self.conv = DoubleConv(in_channels, out_channels, in_channels // 2)
+            return
         self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
         # parameter memory ordered (a, b, co, ci): the GEMM's [4*Co][Ci] weight matrix, no re-layout per step
         w = self.up.weight.data
@@ -87,6 +94,8 @@ class Up(nn.Module):
         self.conv = DoubleConv(in_channels, out_channels)
 
     def forward(self, x1, x2):
+        if getattr(self, 'bilinear', False):
+            return self.conv(C.cat_pad(x2, C.upsample_bilinear2x(x1)))            # src/Unet.py:56-68
         return self.conv(C.up_cat(x1, self.up.weight, self.up.bias, x2))
 
 

@@ -341,6 +341,79 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------ bilinear x2 up-sampling, align_corners=True
+// nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) of Up(bilinear=True) (src/Unet.py:48-51), with ATen's
+// arithmetic: scale = (in - 1) / (out - 1) (0 when out == 1), src = scale * dst, i0 = (int)src, i1 = i0 + (i0 < in - 1),
+// lambda1 = src - i0, lambda0 = 1 - lambda1.
+__device__ __forceinline__ void up2_coord(int o, int in, float scale, int& i0, int& i1, float& l0, float& l1) {
+  const float src = scale * (float)o;
+  i0 = (int)src;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.0f - l1;
+}
+
+__global__ void __launch_bounds__(256) upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int Nimg,
+                                                             int H, int W, int C, float sy, float sx) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  long long total = (long long)Nimg * Ho * Wo * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long long p = i / C;
+    int xo = (int)(p % Wo);
+    p /= Wo;
+    int yo = (int)(p % Ho);
+    int n = (int)(p / Ho);
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    up2_coord(yo, H, sy, y0, y1, ly0, ly1);
+    up2_coord(xo, W, sx, x0, x1, lx0, lx1);
+    const float* b = x + (long long)n * H * W * C + c;
+    float v00 = b[((long long)y0 * W + x0) * C], v01 = b[((long long)y0 * W + x1) * C];
+    float v10 = b[((long long)y1 * W + x0) * C], v11 = b[((long long)y1 * W + x1) * C];
+    y[i] = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+  }
+}
+
+// gather form of the backward (no atomics): input pixel (yy, xx) collects, over the few output rows / columns whose
+// source interval touches it, the weight the forward gave it
+__global__ void __launch_bounds__(256) upsample2x_bwd_kernel(const float* __restrict__ gy, float* __restrict__ dx, int Nimg,
+                                                             int H, int W, int C, float sy, float sx) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  long long total = (long long)Nimg * H * W * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long long p = i / C;
+    int xx = (int)(p % W);
+    p /= W;
+    int yy = (int)(p % H);
+    int n = (int)(p / H);
+    // candidate outputs: src in (yy - 1, yy + 1)  <=>  o in ((yy - 1) / s, (yy + 1) / s); widened by one on both sides
+    int oy_lo = sy > 0.f ? (int)floorf((float)(yy - 1) / sy) - 1 : 0, oy_hi = sy > 0.f ? (int)ceilf((float)(yy + 1) / sy) + 1 : Ho - 1;
+    int ox_lo = sx > 0.f ? (int)floorf((float)(xx - 1) / sx) - 1 : 0, ox_hi = sx > 0.f ? (int)ceilf((float)(xx + 1) / sx) + 1 : Wo - 1;
+    oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
+    oy_hi = oy_hi > Ho - 1 ? Ho - 1 : oy_hi; ox_hi = ox_hi > Wo - 1 ? Wo - 1 : ox_hi;
+    float acc = 0.f;
+    const float* g = gy + (long long)n * Ho * Wo * C + c;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1;
+      float ly0, ly1;
+      up2_coord(oy, H, sy, y0, y1, ly0, ly1);
+      float wy = (y0 == yy ? ly0 : 0.f) + (y1 == yy ? ly1 : 0.f);
+      if (wy == 0.f && y0 != yy && y1 != yy) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1;
+        float lx0, lx1;
+        up2_coord(ox, W, sx, x0, x1, lx0, lx1);
+        if (x0 != xx && x1 != xx) continue;
+        float wx = (x0 == xx ? lx0 : 0.f) + (x1 == xx ? lx1 : 0.f);
+        acc += wy * wx * g[((long long)oy * Wo + ox) * C];
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
 // ------------------------------------------------------------------ pooling
 __global__ void __launch_bounds__(256) pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int Nimg, int H,
                                                        int W, int C, int mode) {
@@ -601,6 +674,26 @@ int mmft_bn_train_bwd(const float* gy, const float* x, const float* y, const flo
     hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_grid(total)), dim3(256), 0, st, gy, x, y, gamma, save_mean,
                        save_invstd, coef, dx, rows, C, total, relu, groups, dgamma, dbeta, beta);
   return check_launch("bn_train_bwd");
+}
+
+static inline float up2_scale(int in) { return 2 * in > 1 ? (float)(in - 1) / (float)(2 * in - 1) : 0.f; }
+
+int mmft_upsample_bilinear2x_fwd(const float* x, float* y, int Nimg, int H, int W, int C, int device, void* stream) {
+  MMFT_REQUIRE(x && y && Nimg > 0 && H > 0 && W > 0 && C > 0, "upsample_bilinear2x_fwd: bad args");
+  DeviceGuard dg(device);
+  long long total = (long long)Nimg * 4 * H * W * C;
+  MMFT_LAUNCH("upsample2x_fwd_kernel", 0.0, 4.0 * total * 1.25, upsample2x_fwd_kernel, dim3(ew_grid(total)), dim3(256),
+              (hipStream_t)stream, x, y, Nimg, H, W, C, up2_scale(H), up2_scale(W));
+  return check_launch("upsample_bilinear2x_fwd");
+}
+
+int mmft_upsample_bilinear2x_bwd(const float* gy, float* dx, int Nimg, int H, int W, int C, int device, void* stream) {
+  MMFT_REQUIRE(gy && dx && Nimg > 0 && H > 0 && W > 0 && C > 0, "upsample_bilinear2x_bwd: bad args");
+  DeviceGuard dg(device);
+  long long total = (long long)Nimg * H * W * C;
+  MMFT_LAUNCH("upsample2x_bwd_kernel", 0.0, 4.0 * total * 5.0, upsample2x_bwd_kernel, dim3(ew_grid(total)), dim3(256),
+              (hipStream_t)stream, gy, dx, Nimg, H, W, C, up2_scale(H), up2_scale(W));
+  return check_launch("upsample_bilinear2x_bwd");
 }
 
 int mmft_pool2x2_fwd(const float* x, float* y, int Nimg, int H, int W, int C, int mode, int device, void* stream) {

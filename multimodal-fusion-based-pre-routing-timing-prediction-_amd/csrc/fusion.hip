@@ -319,6 +319,95 @@ __global__ void __launch_bounds__(1024) eval_sums_kernel(const float* __restrict
   }
 }
 
+// nn.CrossEntropyLoss() (mean) over logits [n][C] and int64 class labels (task == 'cls', src/train.py:32,516-518), with the
+// gradient (softmax - onehot) / n produced by the same pass; out (optional, fp64[6]) = n, sum of losses, tp, fp, tn, fn with
+// predicted class = argmax (first maximum, as th.argmax) and "positive" = class != 0 (src/train.py:536-541).
+__global__ void __launch_bounds__(1024) cross_entropy_kernel(const float* __restrict__ z, const long long* __restrict__ y, int n,
+                                                             int C, float* __restrict__ loss, float* __restrict__ grad,
+                                                             double* __restrict__ out) {
+  __shared__ double red[5][1024 / 64];
+  double a[5] = {0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float* r = z + (long long)i * C;
+    float mx = r[0];
+    int arg = 0;
+    for (int c = 1; c < C; ++c)
+      if (r[c] > mx) {
+        mx = r[c];
+        arg = c;
+      }
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(r[c] - mx);
+    const int yi = (int)y[i];
+    a[0] += (double)(mx + logf(s) - r[yi]);
+    if (grad) {
+      const float inv = 1.0f / s, sc = 1.0f / (float)n;
+      for (int c = 0; c < C; ++c) grad[(long long)i * C + c] = (expf(r[c] - mx) * inv - (c == yi ? 1.0f : 0.0f)) * sc;
+    }
+    const bool pp = arg != 0, ap = yi != 0;
+    a[1] += (pp && ap) ? 1.0 : 0.0;
+    a[2] += (pp && !ap) ? 1.0 : 0.0;
+    a[3] += (!pp && !ap) ? 1.0 : 0.0;
+    a[4] += (!pp && ap) ? 1.0 : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    double v = a[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    double s = 0.0;
+    for (int w = 0; w < 1024 / 64; ++w) s += red[threadIdx.x][w];
+    if (threadIdx.x == 0 && loss) loss[0] = (float)(s / (double)n);
+    if (out) {
+      if (threadIdx.x == 0) out[0] = (double)n;
+      out[threadIdx.x + 1] = s;
+    }
+  }
+}
+
+// the same ten sums per topological level (src/test.py:211-216 prints R2 and MAPE per level): block l filters the
+// batch rows whose level id is l.  T is ~10^4 and L ~10^2, so every block simply scans the whole batch.
+__global__ void __launch_bounds__(1024) eval_sums_by_level_kernel(const float* __restrict__ pred, const float* __restrict__ y,
+                                                                  const float* __restrict__ req,
+                                                                  const float* __restrict__ label,
+                                                                  const int* __restrict__ level, int n,
+                                                                  double* __restrict__ out) {
+  __shared__ double red[10][1024 / 64];
+  const int l = blockIdx.x;
+  double a[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    if (level[i] != l) continue;
+    double p = pred[i], t = y[i];
+    double d = p - t;
+    a[0] += 1.0;
+    a[1] += t;
+    a[2] += t * t;
+    a[3] += d * d;
+    a[4] += fabs(d);
+    if (t != 0.0) a[5] += fabs(d) / fabs(t);
+    bool pc = ((double)req[i] - p) < 0.0, ac = label[i] != 0.f;
+    a[6] += (pc && ac) ? 1.0 : 0.0;
+    a[7] += (pc && !ac) ? 1.0 : 0.0;
+    a[8] += (!pc && !ac) ? 1.0 : 0.0;
+    a[9] += (!pc && ac) ? 1.0 : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    double v = a[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 10) {
+    double s = 0.0;
+    for (int w = 0; w < 1024 / 64; ++w) s += red[threadIdx.x][w];
+    out[(long long)l * 10 + threadIdx.x] = s;
+  }
+}
+
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float step_size, float beta1,
                                                    float beta2, float eps, float wd, float bc2_sqrt, float gscale,
@@ -503,6 +592,27 @@ int mmft_eval_sums(const float* pred, const float* arrival, const float* require
   DeviceGuard dg(device);
   hipLaunchKernelGGL(eval_sums_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, arrival, required, label, n, out);
   return check_launch("eval_sums");
+}
+
+int mmft_cross_entropy_fwd_bwd(const float* logits, const long long* labels, int n, int C, float* loss, float* grad,
+                               double* eval_out, int device, void* stream) {
+  MMFT_REQUIRE(logits && labels && (loss || eval_out) && n > 0 && n <= (1 << 24) && C >= 2 && C <= 1024,
+               "cross_entropy_fwd_bwd: bad args");
+  DeviceGuard dg(device);
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, labels, n, C, loss, grad,
+                     eval_out);
+  return check_launch("cross_entropy_fwd_bwd");
+}
+
+int mmft_eval_sums_by_level(const float* pred, const float* arrival, const float* required, const float* label,
+                            const int* level, int n, int num_levels, double* out, int device, void* stream) {
+  MMFT_REQUIRE(pred && arrival && required && label && level && out && n > 0 && n <= (1 << 24) && num_levels > 0 &&
+                   num_levels <= 65535,
+               "eval_sums_by_level: bad args");
+  DeviceGuard dg(device);
+  hipLaunchKernelGGL(eval_sums_by_level_kernel, dim3(num_levels), dim3(1024), 0, (hipStream_t)stream, pred, arrival, required,
+                     label, level, n, out);
+  return check_launch("eval_sums_by_level");
 }
 
 int mmft_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,

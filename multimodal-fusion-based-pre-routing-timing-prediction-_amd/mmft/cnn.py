@@ -102,6 +102,22 @@ def pool2x2(x, mode):
     return Pool2x2Fn.apply(x, mode)
 
 
+class UpsampleBilinear2xFn(torch.autograd.Function):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)  (src/Unet.py:50)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.upsample_bilinear2x_fwd(ops.to_nhwc(x))
+
+    @staticmethod
+    def backward(ctx, gy):
+        return ops.upsample_bilinear2x_bwd(ops.to_nhwc(gy))
+
+
+def upsample_bilinear2x(x):
+    return UpsampleBilinear2xFn.apply(x)
+
+
 def _flat(t):
     """contiguous-memory view of a contiguous or channels_last tensor (None otherwise)."""
     if t.is_contiguous():

@@ -243,6 +243,43 @@ def mse_loss(pred, target):
     return MseFn.apply(pred, target)
 
 
+class CrossEntropyFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss() (mean) of the classification task (src/train.py:32,516-518), gradient from the same kernel."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        z = logits if logits.is_contiguous() else logits.contiguous()
+        ops._chk(z, 'logits')
+        ops._chk(labels, 'labels', torch.int64)
+        if z.dim() != 2 or labels.dim() != 1 or labels.numel() != z.shape[0] or not labels.is_contiguous():
+            raise ValueError('cross_entropy: logits [T, C] and int64 labels [T] required')
+        loss = torch.empty(1, dtype=torch.float32, device=z.device)
+        grad = torch.empty_like(z)
+        dev, st = lib.stream_args(z)
+        lib.call('mmft_cross_entropy_fwd_bwd', z, labels, z.shape[0], z.shape[1], loss, grad, None, dev, st)
+        ctx.save_for_backward(grad)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        (grad,) = ctx.saved_tensors
+        return grad * gl, None
+
+
+def cross_entropy_loss(logits, labels):
+    return CrossEntropyFn.apply(logits, labels)
+
+
+def cls_eval_sums(logits, labels):
+    """fp64[6]: n, sum of per-row losses, tp, fp, tn, fn (argmax prediction; positive = class != 0)."""
+    z = logits if logits.is_contiguous() else logits.contiguous()
+    ops._chk(z, 'logits'); ops._chk(labels, 'labels', torch.int64)
+    out = torch.empty(6, dtype=torch.float64, device=z.device)
+    dev, st = lib.stream_args(z)
+    lib.call('mmft_cross_entropy_fwd_bwd', z, labels, z.shape[0], z.shape[1], None, None, out, dev, st)
+    return out
+
+
 class FlatAdam:
     """torch.optim.Adam(params, lr, weight_decay) semantics (src/train.py:431-435) on ONE flat fp32 buffer.
 

@@ -650,6 +650,26 @@ def pool2x2_bwd(x, gy, mode):
     return dx
 
 
+def upsample_bilinear2x_fwd(x):
+    _nhwc(x, 'x')
+    N, C, H, W = x.shape
+    y = empty_nhwc(N, C, 2 * H, 2 * W, x.device)
+    dev, st = lib.stream_args(x)
+    lib.call('mmft_upsample_bilinear2x_fwd', x, y, N, H, W, C, dev, st)
+    return y
+
+
+def upsample_bilinear2x_bwd(gy):
+    _nhwc(gy, 'gy')
+    N, C, H2, W2 = gy.shape
+    if H2 % 2 or W2 % 2:
+        raise ValueError('upsample_bilinear2x_bwd: gradient of a x2 up-sampling expected')
+    dx = empty_nhwc(N, C, H2 // 2, W2 // 2, gy.device)
+    dev, st = lib.stream_args(gy)
+    lib.call('mmft_upsample_bilinear2x_bwd', gy, dx, N, H2 // 2, W2 // 2, C, dev, st)
+    return dx
+
+
 def pixel_shuffle2(t, bias, N, H, W, Co, out=None, c_off=0):
     """t: [N*H*W, 4*Co] rows -> (N,Co,2H,2W) channels_last, + bias[co]; with `out` given: into its channel slice
     [c_off, c_off + Co)."""

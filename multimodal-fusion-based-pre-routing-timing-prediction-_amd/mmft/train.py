@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from .pingraph import PinGraph
-from .fusion import PathMasks, MaskedPathMap, FlatAdam, mse_loss, batch_links
+from .fusion import PathMasks, MaskedPathMap, FlatAdam, mse_loss, cross_entropy_loss, batch_links
 
 
 def build_models(map_size=128, out_dim=128, cell_feat_dim=36, net_feat_dim=2, cnn_outdim=128, pooling='max',
@@ -167,11 +167,13 @@ class DesignBatch:
 
 class TrainStep:
     def __init__(self, pmodel, cnn, designs, device, lr=1e-3, weight_decay=0.0, fused_optimizer=True, world_size=1,
-                 mode='sweep', overlap=True, with_optimizer=True):
+                 mode='sweep', overlap=True, with_optimizer=True, task='reg'):
         """mode='dropin': per-level model() calls exactly as src/train.py:490-511;
-        mode='sweep': PathModel.forward_sweep, same arithmetic with level-invariant work hoisted."""
-        assert mode in ('dropin', 'sweep')
-        self.mode = mode
+        mode='sweep': PathModel.forward_sweep, same arithmetic with level-invariant work hoisted.
+        task='reg': MSE on the arrival time (nlabels = 1); task='cls': CrossEntropy on ndata['label'] with a
+        nlabels-wide head (src/train.py:32,513-522; src/options.py:32,49)."""
+        assert mode in ('dropin', 'sweep') and task in ('reg', 'cls')
+        self.mode, self.task = mode, task
         self.overlap = overlap and mode == 'sweep'
         self.side = torch.cuda.Stream(device=device) if self.overlap else None
         self.pmodel, self.cnn = pmodel, cnn
@@ -246,14 +248,20 @@ class TrainStep:
                 hats.append(cur)
         return torch.cat(hats, 0), ends_d, ends_h
 
+    def loss(self, hats, ends_d):
+        """src/train.py:513-522: CrossEntropy(label_hats, labels) for task 'cls', MSE(label_hats, arrival_time) for 'reg'."""
+        if self.task == 'cls':
+            labels = self.batch.graph.ndata['label'][ends_d.long()].squeeze(-1).contiguous()
+            return cross_entropy_loss(hats, labels)
+        return mse_loss(hats, self.batch.arrival[ends_d.long()].squeeze(-1))
+
     def step(self, path_ids_per_design):
         """One mini-batch: forward, MSE on arrival time, backward, (all-reduce,) Adam.
         Returns (loss tensor, predictions, target node ids); `self.last_ends` holds the endpoints' device-side
         (renumbered) node ids, the index space of `self.batch.arrival` / `.required`."""
         hats, ends_d, ends_h = self.forward(path_ids_per_design)
         self.last_ends = ends_d
-        arrival = self.batch.arrival[ends_d.long()].squeeze(-1)                            # src/train.py:520-522
-        loss = mse_loss(hats, arrival)
+        loss = self.loss(hats, ends_d)
         self.optim.zero_grad()
         if self.reducer is not None:
             self.reducer.begin()
@@ -297,7 +305,7 @@ class GraphedTrainStep:
         with torch.cuda.stream(warm):
             hats0, ends0, _ = ts.forward(example_path_ids)
             ts.optim.zero_grad()
-            loss0 = mse_loss(hats0, b.arrival[ends0.long()].squeeze(-1))
+            loss0 = ts.loss(hats0, ends0)
             loss0.backward()
             ts.optim.zero_grad()
             del hats0, ends0, loss0
@@ -315,8 +323,7 @@ class GraphedTrainStep:
         # thread_local: RCCL's watchdog thread may query events while this thread captures
         with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             hats, ends_d, _ = ts.forward(None, _sel=sel)
-            arrival = b.arrival[ends_d.long()].squeeze(-1)
-            loss = mse_loss(hats, arrival)
+            loss = ts.loss(hats, ends_d)
             ts.optim.zero_grad()
             if ts.reducer is not None:
                 loss.backward()                      # the buckets are reduced behind every replay (GradReducer)

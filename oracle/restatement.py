@@ -188,11 +188,20 @@ def _pool(x, pooling):
     return F.max_pool2d(x, 2) if pooling == 'max' else F.avg_pool2d(x, 2)
 
 
-def _up(p, prefix, x1, x2, update_running):
-    x1 = F.conv_transpose2d(x1, p[prefix + 'up.weight'], p[prefix + 'up.bias'], stride=2)
+def _up(p, prefix, x1, x2, update_running, bilinear=False):
+    """Up.forward (src/Unet.py:56-68); bilinear=True: nn.Upsample(scale_factor=2, 'bilinear', align_corners=True) (:50)."""
+    if bilinear:
+        x1 = F.interpolate(x1, scale_factor=2, mode='bilinear', align_corners=True)
+    else:
+        x1 = F.conv_transpose2d(x1, p[prefix + 'up.weight'], p[prefix + 'up.bias'], stride=2)
     dy, dx = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
     x1 = F.pad(x1, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
     return _double_conv(p, prefix + 'conv.', torch.cat([x2, x1], dim=1), update_running)
+
+
+def up_block(p, x1, x2, bilinear, update_running=True):
+    """One Up module on its own (state_dict keys 'up.*' / 'conv.double_conv.*')."""
+    return _up(p, '', x1, x2, update_running, bilinear)
 
 
 def unet_forward(p, x, pooling='max', update_running=True):

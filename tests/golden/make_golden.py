@@ -263,6 +263,41 @@ def golden_unet(ref_unet):
                      nbt=nsd['inc.double_conv.1.num_batches_tracked'])
 
 
+def golden_up_bilinear(ref_unet):
+    """Up(in, out, bilinear=True) (src/Unet.py:48-51): the reference module on an even and an odd (padded) size.
+    UNet(pooling, bilinear=True) itself cannot run in the reference (up3 yields 8 channels, OutConv expects 16)."""
+    try:
+        ref_unet.UNet('max', bilinear=True)(torch.zeros(1, 3, 16, 16))
+        raise AssertionError('reference UNet(bilinear=True) unexpectedly runs')
+    except RuntimeError as e:
+        assert 'channels' in str(e)
+    for tag, (s1, s2), seed in (('even', ((1, 16, 8, 8), (1, 16, 16, 16)), 81), ('odd', ((2, 16, 7, 9), (2, 16, 15, 19)), 82)):
+        for dtype, tol in ((torch.float32, 2e-6), (torch.float64, 1e-12)):
+            up = ref_unet.Up(32, 16, bilinear=True).to(dtype)
+            sd = det_state_dict(up, seed)
+            up.load_state_dict({k: v.to(dtype) if v.dtype.is_floating_point else v for k, v in sd.items()})
+            up.train()
+            x1 = torch.from_numpy(det_uniform(s1, seed + 100)).to(dtype).requires_grad_(True)
+            x2 = torch.from_numpy(det_uniform(s2, seed + 200)).to(dtype).requires_grad_(True)
+            y = up(x1, x2)
+            wts = torch.from_numpy(det_uniform(tuple(y.shape), seed + 300)).to(dtype)
+            (y * wts).sum().backward()
+            p = {k: (v.to(dtype).clone().requires_grad_(True) if (v.dtype.is_floating_point and 'running' not in k)
+                     else (v.to(dtype).clone() if v.dtype.is_floating_point else v.clone())) for k, v in sd.items()}
+            a1, a2 = x1.detach().clone().requires_grad_(True), x2.detach().clone().requires_grad_(True)
+            yo = R.up_block(p, a1, a2, bilinear=True)
+            (yo * wts).sum().backward()
+            check(f'up bilinear {tag} {dtype}', yo, y, tol)
+            check('up bilinear dx1', a1.grad, x1.grad, tol * 50)
+            check('up bilinear dx2', a2.grad, x2.grad, tol * 50)
+            g = dict(up.named_parameters())
+            for k in g:
+                check('up bilinear grad ' + k, p[k].grad, g[k].grad, tol * 50)
+            if dtype == torch.float32:
+                save(f'up_bilinear_{tag}', seed=seed, out=y, dx1=x1.grad, dx2=x2.grad,
+                     g_conv0=g['conv.double_conv.0.weight'].grad, g_bn1_w=g['conv.double_conv.1.weight'].grad)
+
+
 def golden_layoutnet(ref_model):
     for pooling, seed in (('max', 21), ('avg', 22)):
         net = ref_model.LayoutNet(pooling)
@@ -531,6 +566,7 @@ def main():
     golden_cell_reduce(ref_model)
     golden_layoutnet(ref_model)
     golden_unet(ref_unet)
+    golden_up_bilinear(ref_unet)
     golden_sweep(ref_model)
     golden_attention(ref_model)
     print('all fixtures written; oracle restatement agrees with the reference on every one of them')

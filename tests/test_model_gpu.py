@@ -107,6 +107,30 @@ def test_unet_golden(dev, name, pooling, hw):
     close(y3, g['out'], what='3-D input')
 
 
+@pytest.mark.parametrize('tag,s1,s2,seed', [('even', (1, 16, 8, 8), (1, 16, 16, 16), 81), ('odd', (2, 16, 7, 9), (2, 16, 15, 19), 82)])
+def test_up_bilinear_golden(dev, tag, s1, s2, seed):
+    """Up(32, 16, bilinear=True) (src/Unet.py:48-51): align_corners=True x2 up-sampling kernel (forward + gather backward),
+    centre padding to the skip size, concat, DoubleConv - against the reference module's output and gradients."""
+    import Unet
+    g = gold('up_bilinear_' + tag)
+    up = load_det(Unet.Up(32, 16, bilinear=True), seed, dev)
+    up.train()
+    x1 = torch.from_numpy(det_uniform(s1, seed + 100)).to(dev).requires_grad_(True)
+    x2 = torch.from_numpy(det_uniform(s2, seed + 200)).to(dev).requires_grad_(True)
+    y = up(x1, x2)
+    wts = torch.from_numpy(det_uniform(tuple(y.shape), seed + 300)).to(dev)
+    (y * wts).sum().backward()
+    close(y, g['out'], what='out')
+    close(x1.grad, g['dx1'], 2e-4, 'dx1')
+    close(x2.grad, g['dx2'], 2e-4, 'dx2')
+    close(up.conv.double_conv[0].weight.grad, g['g_conv0'], 2e-4, 'g_conv0')
+    close(up.conv.double_conv[1].weight.grad, g['g_bn1_w'], 2e-4, 'g_bn1_w')
+    # the whole UNet with bilinear=True is unusable in the reference too (up3: 8 channels, OutConv: 16) - same failure
+    net = Unet.UNet('max', bilinear=True).to(dev)
+    with pytest.raises((ValueError, RuntimeError), match='channels'):
+        net(torch.zeros(1, 3, 16, 16, device=dev))
+
+
 @pytest.mark.parametrize('pooling', ['max', 'avg'])
 def test_layoutnet_golden(dev, pooling):
     import model
@@ -488,6 +512,105 @@ def test_eval_metrics_match_reference_formulas(dev):
     fp = int(((pc != 0) & (lab == 0)).sum()); tn = int(((pc == 0) & (lab == 0)).sum())
     assert (m['tp'], m['fp'], m['tn'], m['fn']) == (tp, fp, tn, fn)
     assert abs(m['recall'] - tp / (tp + fn)) < 1e-12 and abs(m['precision'] - tp / (tp + fp)) < 1e-12
+
+
+def test_per_level_metrics_and_validate_loop(dev):
+    """Per-level R2 / MAPE (src/test.py:211-216) from the segmented sums kernel against the reference's formulas, and the
+    per-design validate() loop (src/train.py:137-291) against the fp64 oracle's predictions on every design."""
+    from mmft.evaluate import eval_sums_by_level, level_metrics_from_sums, validate_designs
+    from mmft.synth import synth_design
+    from mmft.train import build_models
+    torch.manual_seed(1)
+    n, L = 3000, 9
+    lv = torch.randint(0, L, (n,), dtype=torch.int32)
+    lv[lv == 4] = 5                                                   # an empty level
+    lv[:1] = 7
+    lv[1:][lv[1:] == 7] = 6                                           # a level with ONE prediction: not reported
+    y = torch.rand(n) * 2 + 0.1
+    p = y + 0.2 * torch.randn(n)
+    req = torch.full((n,), 1.2)
+    lab = ((req - y) < 0).float()
+    rows = eval_sums_by_level(p.to(dev), y.to(dev), req.to(dev), lab.to(dev), lv.to(dev), L).cpu().tolist()
+    got = {m['level']: m for m in level_metrics_from_sums(rows)}
+    assert 4 not in got and 7 not in got
+    for l in range(L):
+        sel = lv == l
+        if int(sel.sum()) < 2:
+            continue
+        pd, yd = p[sel].double(), y[sel].double()
+        assert got[l]['n'] == int(sel.sum())
+        assert abs(got[l]['r2'] - float(R.r2_score(pd, yd))) < 1e-9
+        assert abs(got[l]['mape'] - float(((pd - yd) / yd).abs().mean())) < 1e-9
+    # validate(): one batch per design over all of its paths
+    designs = [synth_design(N=2048, L=12, tile=32, seed=600 + i, end_frac=0.25) for i in range(2)]
+    pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=13)
+    pm_state = {k: v.detach().cpu().clone() for k, v in pmodel.state_dict().items()}
+    pc_state = {k: v.detach().cpu().clone() for k, v in cnn.state_dict().items()}
+    res = validate_designs(pmodel, cnn, designs, dev)
+    assert len(res['cases']) == 2 and set(res['overall']) >= {'loss', 'r2', 'f1', 'endpoint_slack_mae'}
+    for d, case in zip(designs, res['cases']):
+        orc = R.OracleTrainer(pm_state, pc_state, dtype=torch.float64)
+        with torch.no_grad():
+            hats, tl, _ = R.sweep_forward(orc.pm, orc.pc, d, R.design_csr(d), list(range(d.num_paths)), update_running=False,
+                                          dtype=torch.float64)
+        arr = torch.from_numpy(d.arrival_time).double()[torch.tensor(tl)].squeeze(-1)
+        assert case['n'] == d.num_paths
+        assert abs(case['loss'] - float(((hats - arr) ** 2).mean())) < 1e-4 * float(((hats - arr) ** 2).mean()) + 1e-9
+        assert abs(case['endpoint_slack_mae'] - float((hats - arr).abs().mean())) < 1e-4
+        lvl = torch.from_numpy(d.path2level[np.argsort(d.path2level, kind='stable')])
+        for m in case['levels']:
+            sel = lvl == m['level']
+            assert m['n'] == int(sel.sum())
+            assert abs(m['mape'] - float(((hats[sel] - arr[sel]) / arr[sel]).abs().mean())) < 1e-4
+    assert abs(res['overall']['loss'] - np.mean([c['loss'] for c in res['cases']])) < 1e-12
+
+
+def test_classification_task(dev):
+    """--task cls (src/train.py:32,513-519; src/options.py:32,49): a 2-wide head, CrossEntropy on ndata['label'], argmax
+    prediction.  Loss and gradients of one step against the fp64 oracle, then a few optimizer steps and the evaluation."""
+    from mmft.synth import synth_design
+    from mmft.train import build_models, TrainStep, GraphedTrainStep
+    from mmft.evaluate import validate
+    d = synth_design(N=4096, L=16, tile=32, seed=41, end_frac=0.25)
+    # make ~40 % of the endpoints "critical" so that both classes occur
+    ends = d.path2endpoint
+    d.label[ends[::5], 0] = 1
+    d.label[ends[1::5], 0] = 1
+    pmodel, cnn = build_models(map_size=d.map_size, device=dev, seed=17, nlabels=2)
+    pm_state = {k: v.detach().cpu().clone() for k, v in pmodel.state_dict().items()}
+    pc_state = {k: v.detach().cpu().clone() for k, v in cnn.state_dict().items()}
+    ts = TrainStep(pmodel, cnn, [d], dev, task='cls')
+    ids = np.random.default_rng(3).permutation(d.num_paths)[:96].tolist()
+    hats, ends_d, ends_h = ts.forward([ids])
+    assert tuple(hats.shape) == (96, 2)
+    loss = ts.loss(hats, ends_d)
+    ts.optim.zero_grad()
+    loss.backward()
+    orc = R.OracleTrainer(pm_state, pc_state, dtype=torch.float64)
+    hats_o, tl, _ = orc.forward(d, R.design_csr(d), ids)
+    assert ends_h.tolist() == tl
+    lab = torch.from_numpy(d.label)[torch.tensor(tl)].squeeze(-1)
+    loss_o = torch.nn.functional.cross_entropy(hats_o, lab)
+    loss_o.backward()
+    close(hats, hats_o, TOL, 'logits')
+    close(loss, loss_o, TOL, 'cross entropy')
+    for k in ('mlp_fuse.layers.2.weight', 'mlp_fuse.layers.0.bias', 'fcn.weight', 'gnn.fc_cell_neigh.layers.0.weight'):
+        close(dict(pmodel.named_parameters())[k].grad, orc.pm[k].grad, 2e-4, k)
+    close(cnn.inc.double_conv[0].weight.grad, orc.pc['inc.double_conv.0.weight'].grad, 5e-4, 'cnn grad')
+    # training + evaluation
+    rng = np.random.default_rng(4)
+    gs = GraphedTrainStep(ts, [ids], warmup=0)
+    losses = [float(gs.step([rng.permutation(d.num_paths)[:96].tolist()])[0]) for _ in range(30)]
+    assert np.mean(losses[-5:]) < np.mean(losses[:5])
+    ev = TrainStep(pmodel, cnn, [d], dev, overlap=False, with_optimizer=False, task='cls')
+    m = validate(ev)
+    with torch.no_grad():
+        z, e_d, _ = ev.forward([np.arange(d.num_paths)])
+        y = ev.batch.graph.ndata['label'][e_d.long()].squeeze(-1)
+    pred = torch.argmax(torch.softmax(z, 1), dim=1)                                     # src/train.py:516
+    assert m['n'] == d.num_paths and abs(m['acc'] - float((pred == y).float().mean())) < 1e-9
+    assert (m['tp'], m['fn']) == (int(((pred != 0) & (y != 0)).sum()), int(((pred == 0) & (y != 0)).sum()))
+    assert abs(m['loss'] - float(torch.nn.functional.cross_entropy(z.double(), y))) < 1e-5
 
 
 def test_training_trajectory_vs_oracle(dev):

@@ -245,3 +245,31 @@ def test_sweep_attention():
     for k in ('fc_key.weight', 'fc_attn.weight', 'fc_cell_neigh.layers.0.weight', 'fc_net_self.layers.2.bias'):
         close(p['gnn.' + k].grad, g['g_' + k.replace('.', '_')], 2e-4, k)
     assert p['gnn.fc_net_drive.layers.0.weight'].grad is None and p['gnn.fc_attn2.weight'].grad is None
+
+
+def _up_shapes():
+    s = {'conv.double_conv.0.weight': (16, 32, 3, 3), 'conv.double_conv.3.weight': (16, 16, 3, 3)}
+    for i in (1, 4):
+        for n in ('weight', 'bias', 'running_mean', 'running_var'):
+            s[f'conv.double_conv.{i}.{n}'] = (16,)
+        s[f'conv.double_conv.{i}.num_batches_tracked'] = ()
+    # state_dict order of the reference module: conv.double_conv.0, .1.*, .3, .4.*
+    order = ['conv.double_conv.0.weight'] + [f'conv.double_conv.1.{n}' for n in ('weight', 'bias', 'running_mean', 'running_var', 'num_batches_tracked')] + \
+            ['conv.double_conv.3.weight'] + [f'conv.double_conv.4.{n}' for n in ('weight', 'bias', 'running_mean', 'running_var', 'num_batches_tracked')]
+    return {k: s[k] for k in order}
+
+
+@pytest.mark.parametrize('tag,s1,s2,seed', [('even', (1, 16, 8, 8), (1, 16, 16, 16), 81), ('odd', (2, 16, 7, 9), (2, 16, 15, 19), 82)])
+def test_up_bilinear(tag, s1, s2, seed):
+    """Up(32, 16, bilinear=True) (src/Unet.py:48-51,56-68): restatement vs the reference module's output and gradients."""
+    g = gold('up_bilinear_' + tag)
+    sd = det_state_dict(_Shape(_up_shapes()), seed)
+    p = {k: (v.clone().requires_grad_(True) if (v.dtype.is_floating_point and 'running' not in k) else v.clone()) for k, v in sd.items()}
+    x1 = torch.from_numpy(det_uniform(s1, seed + 100)).requires_grad_(True)
+    x2 = torch.from_numpy(det_uniform(s2, seed + 200)).requires_grad_(True)
+    y = R.up_block(p, x1, x2, bilinear=True)
+    (y * torch.from_numpy(det_uniform(tuple(y.shape), seed + 300))).sum().backward()
+    close(y, g['out'], 2e-6, 'out')
+    close(x1.grad, g['dx1'], 1e-4, 'dx1')
+    close(x2.grad, g['dx2'], 1e-4, 'dx2')
+    close(p['conv.double_conv.0.weight'].grad, g['g_conv0'], 1e-4, 'g_conv0')
