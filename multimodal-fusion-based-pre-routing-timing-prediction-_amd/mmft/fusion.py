@@ -147,6 +147,27 @@ class MaskedPathMap:
         return (self.paths.numel(), self.masks.P)
 
 
+# Per-step cache of what the masked projection derives from (fcn.weight, feat_map) alone: the transposed weight and the
+# block-prefix table.  The per-level drop-in loop calls fcn once per level with the SAME weight and feature map
+# (src/train.py:500-503); without the cache every level re-transposes 8 MB and rebuilds the 67 MB prefix table.
+# Valid while the same tensor objects are alive and unmodified (weak references + versions + the parameter epoch that the
+# fused optimizer bumps, since it rewrites parameters through raw pointers) and the work was issued on the same stream.
+_FC_CACHE = {}
+
+
+def _fc_cached(kind, deps, build):
+    import weakref
+    if torch.cuda.is_current_stream_capturing():
+        return build()          # a captured step must contain its own transpose / prefix launches: never reuse, never keep
+    key = tuple((id(t), t._version) for t in deps) + (gradsink.param_epoch(), torch.cuda.current_stream().cuda_stream)
+    e = _FC_CACHE.get(kind)
+    if e is not None and e[0] == key and all(r() is t for r, t in zip(e[1], deps)):
+        return e[2]
+    val = build()
+    _FC_CACHE[kind] = (key, [weakref.ref(t) for t in deps], val)
+    return val
+
+
 class MaskedFcFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat_map, w, b, pm):
@@ -156,14 +177,21 @@ class MaskedFcFn(torch.autograd.Function):
         Dout, P = wc.shape
         T = pm.paths.numel()
         dev, st = lib.stream_args(f)
-        wT = torch.empty((P, Dout), dtype=torch.float32, device=f.device)
-        lib.call('mmft_transpose', wc, wT, Dout, P, dev, st)
+
+        def _wT():
+            t = torch.empty((P, Dout), dtype=torch.float32, device=f.device)
+            lib.call('mmft_transpose', wc, t, Dout, P, dev, st)
+            return t
+        wT = _fc_cached('wT', (w,), _wT)
         out = torch.empty((T, Dout), dtype=torch.float32, device=f.device)
         m = pm.masks
         if USE_RUNS and m.run_block and f.numel() == m.B * P:
             # block-prefix sums of f * wT once per step, then two reads per run of a path instead of one per cell
-            GP = torch.empty((m.B * P, Dout), dtype=torch.float32, device=f.device)
-            lib.call('mmft_masked_fc_prefix', f, wT, GP, m.B, P, Dout, m.run_block, dev, st)
+            def _gp():
+                t = torch.empty((m.B * P, Dout), dtype=torch.float32, device=f.device)
+                lib.call('mmft_masked_fc_prefix', f, wT, t, m.B, P, Dout, m.run_block, dev, st)
+                return t
+            GP = _fc_cached('GP', (w, feat_map), _gp)
             lib.call('mmft_masked_fc_fwd_runs', m.run_ptr, m.run_start, m.run_len, pm.paths, pm.f_off, T, GP, b, out, Dout,
                      m.run_block, dev, st)
         else:
@@ -350,6 +378,7 @@ class FlatAdam:
         lib.call('mmft_adam_step_counted', self.flat_param[lo:hi], self.flat_grad[lo:hi], self.m[lo:hi], self.v[lo:hi],
                  hi - lo, self.state[i], float(self.lr), float(b1), float(b2), float(self.eps), float(self.wd),
                  float(gscale), dev, st)
+        gradsink.params_changed()        # raw-pointer update: Tensor._version does not see it
 
     def step(self, gscale=1.0):
         """One Adam step.  The step counter lives in device memory (`self.state[:, 0]`) and the kernel derives both

@@ -56,6 +56,20 @@ def detach(param):
 def new_step():
     """Called by the owner of the sinks after it has zeroed them (FlatAdam.zero_grad)."""
     _epoch[0] += 1
+    _param_epoch[0] += 1
+
+
+# Bumped whenever parameters may have been rewritten behind torch's back (the fused Adam kernel writes the flat buffer
+# through raw pointers, so Tensor._version does not move): per-step caches derived from parameters key on it.
+_param_epoch = [0]
+
+
+def params_changed():
+    _param_epoch[0] += 1
+
+
+def param_epoch():
+    return _param_epoch[0]
 
 
 def of(param):

@@ -59,6 +59,9 @@ class SweepState:
         self.fold = None                    # static facts for the folded level kernels (PinGraph.fold_schedule)
         self.PRE = None
         self.attn = None                    # attention branch (flag_attn): dict(key, c12, alpha, dcp, o2i)
+        self.spec_lists = None              # speculative drop-in sweep: the level lists it ran with, its token, target rows
+        self.spec_token = None
+        self.spec_tix = []
         self.target_order = None
         self.targets_unique = None
 
@@ -331,6 +334,39 @@ def attention_coefficients(conv):
 
 def level_forward(conv, graph, cur_nodes, targets, level_id):
     """Body of PathConv.forward (both branches)."""
+    seen = graph.__dict__.setdefault('_seen_lists', [])
+    spec_active = False
+    if level_id == 0:
+        spec = graph.__dict__.get('_spec_lists')
+        if len(seen) >= 2 and (spec is None or len(seen) >= len(spec)):
+            spec = graph.__dict__['_spec_lists'] = list(seen)            # the previous sweep's lists, levels 0 .. k
+        del seen[:]
+        if SPECULATE and spec is not None and not torch.is_tensor(cur_nodes) and _same_list(cur_nodes, spec[0]):
+            st, token = _run_sweep(conv, graph, spec, None)
+            st.spec_lists, st.spec_token, st.spec_tix, st.next_level = spec, token, [], 0
+            spec_active = True
+    else:
+        spec_active = graph._sweep is not None and graph._sweep.spec_lists is not None
+    if not torch.is_tensor(cur_nodes):
+        seen.append(cur_nodes)
+    if spec_active:
+        st = graph._sweep
+        if st.h is not graph.ndata['h']:
+            raise RuntimeError("graph.ndata['h'] was replaced in the middle of a sweep; restart from level 0")
+        if level_id != st.next_level:
+            raise RuntimeError(f'PathConv: levels must arrive in increasing order (got {level_id}, expected {st.next_level})')
+        st.next_level = level_id + 1
+        if level_id >= len(st.spec_lists) or torch.is_tensor(cur_nodes) or not _same_list(cur_nodes, st.spec_lists[level_id]):
+            raise RuntimeError(f'PathConv: level {level_id} arrived with a node list that differs from the one this graph was '
+                               f'swept with before - the speculative whole-sweep of the level-0 call used the recorded lists. '
+                               f'Set mmft.sweep.SPECULATE = False for loops whose level lists change between steps.')
+        tix = graph.level_rows(level_id, targets, 'targets')
+        if not tix.numel():
+            return st.h.new_zeros((0, st.D))
+        if st.need_grad:
+            st.spec_tix.append(tix)
+            return TargetGatherFn.apply(st.spec_token, st, tix, graph.__dict__.get('targets_unique'))
+        return ops.gather_rows(st.h, tix)
     if level_id == 0 or graph._sweep is None:
         if level_id != 0:
             raise RuntimeError('PathConv: a sweep must start at level 0 (src/train.py:489-490)')
@@ -480,12 +516,16 @@ class SweepFn(torch.autograd.Function):
                 _cell_neigh_fwd(st, rows, w1g, b1g, w2g, b2g, act)
         ctx.state, ctx.tix, ctx.nparams = st, tix, len(params)
         ctx.has_c12 = c12 is not None
+        if tix is None:
+            # speculative drop-in sweep: the per-level target gathers (TargetGatherFn) hang off this token
+            return st.h.new_zeros(1)
         return ops.gather_rows(st.h, tix) if tix.numel() else st.h.new_zeros((0, st.D))
 
     @staticmethod
     def backward(ctx, gout):
         st, g = ctx.state, ctx.state.graph
-        st.bwd_active = False
+        if ctx.tix is not None:
+            st.bwd_active = False
         # The fills of G / DA (2 x 268 MB per step at config B) may only be skipped when the level lists are a complete
         # schedule of the graph: then every row a pull reads was rewritten earlier in this reverse sweep.  With a
         # partial schedule (fan-in cone, truncated lists) consumers outside it keep rows from an earlier step - or
@@ -493,10 +533,14 @@ class SweepFn(torch.autograd.Function):
         fast = st.complete
         st.begin_backward(zero_da=not fast, zero_g=not fast)
         own = st.tflag if fast else None
-        if ctx.tix.numel():
+        tix = ctx.tix
+        if tix is None:
+            # the TargetGatherFn nodes of this sweep have already zeroed / flagged / filled their rows of G
+            tix = torch.cat(st.spec_tix) if st.spec_tix else st.h.new_zeros(0, dtype=torch.int32)
+        elif tix.numel():
             if fast:
-                ops.target_rows_begin(st.G, ctx.tix, st.tflag)
-            ops.scatter_add_targets(st.G, ctx.tix, gout if gout.is_contiguous() else gout.contiguous(),
+                ops.target_rows_begin(st.G, tix, st.tflag)
+            ops.scatter_add_targets(st.G, tix, gout if gout.is_contiguous() else gout.contiguous(),
                                     order=st.target_order, unique=st.targets_unique)
         P = [_w(p) for p in st.params]
         w1g, w2g = P[8], P[10]
@@ -517,17 +561,35 @@ class SweepFn(torch.autograd.Function):
         if ctx.has_c12:
             rc2 = st.row_sets[2]
             dc = _attn_c12_grad(st, rc2) if rc2 is not None else torch.zeros((2, 1), dtype=torch.float32, device=st.h.device)
-        if ctx.tix.numel() and fast:
-            ops.target_rows_end(ctx.tix, st.tflag)
+        if tix.numel() and fast:
+            ops.target_rows_end(tix, st.tflag)
         st.bwd_active = False
         return (None, None, None, dc, *grads)
 
 
-def sweep_forward_all(conv, graph, level_nodes, targets, target_order=None, targets_unique=None):
-    """All levels of one sweep in one call. level_nodes: list (per level) of python int lists or device int32
-    tensors; targets: device int32 tensor (or list) of node ids whose embeddings are returned, in order.
-    target_order: optional device int32 stable argsort of `targets` (the host has it for free when it packs a
-    step's endpoints); targets_unique: True when the caller knows that no endpoint is repeated."""
+class TargetGatherFn(torch.autograd.Function):
+    """h[targets] of one level of a SPECULATIVE drop-in sweep (the whole sweep ran at the level-0 call).  Backward: zero,
+    flag and fill the endpoint rows of G - the reverse sweep itself is SweepFn.backward, which the engine runs after
+    every node that consumes the sweep's token."""
+
+    @staticmethod
+    def forward(ctx, token, state, tix, unique):
+        ctx.state, ctx.tix, ctx.unique = state, tix, unique
+        return ops.gather_rows(state.h, tix)
+
+    @staticmethod
+    def backward(ctx, gout):
+        st = ctx.state
+        fast = st.complete
+        st.begin_backward(zero_da=not fast, zero_g=not fast)
+        if fast:
+            ops.target_rows_begin(st.G, ctx.tix, st.tflag)
+        ops.scatter_add_targets(st.G, ctx.tix, gout if gout.is_contiguous() else gout.contiguous(), unique=ctx.unique)
+        return st.h.new_zeros(1), None, None, None
+
+
+def _run_sweep(conv, graph, level_nodes, tix, target_order=None, targets_unique=None):
+    """Build the sweep state for the given level lists and run SweepFn (tix None: deferred per-level target gathers)."""
     st = SweepState(graph, conv)
     graph._sweep = st
     st.complete = graph.level_set_is_complete(level_nodes)
@@ -536,7 +598,6 @@ def sweep_forward_all(conv, graph, level_nodes, targets, target_order=None, targ
     level_rows = [graph.level_rows(l, nodes, 'nodes') for l, nodes in enumerate(level_nodes)]
     st.level_meta = [graph.level_meta(l, nodes, st.D) if not torch.is_tensor(nodes) else None
                      for l, nodes in enumerate(level_nodes)]
-    tix = graph.level_rows(-1, targets, 'sweep_targets')
     st.next_level = len(level_rows)
     c12 = None
     if getattr(conv, 'flag_attn', False):
@@ -547,6 +608,28 @@ def sweep_forward_all(conv, graph, level_nodes, targets, target_order=None, targ
                 ops.seg_mean_rows_any(st.net_feat, graph.csr('in', 'net'), level_rows[l], hd)
         graph.ndata['h_drive'] = hd
     if st.need_grad or (c12 is not None and c12.requires_grad):
-        return SweepFn.apply(st, level_rows, tix, c12, *st.params)
+        return st, SweepFn.apply(st, level_rows, tix, c12, *st.params)
     with torch.no_grad():
-        return SweepFn.apply(st, level_rows, tix, c12)
+        return st, SweepFn.apply(st, level_rows, tix, c12)
+
+
+def sweep_forward_all(conv, graph, level_nodes, targets, target_order=None, targets_unique=None):
+    """All levels of one sweep in one call. level_nodes: list (per level) of python int lists or device int32
+    tensors; targets: device int32 tensor (or list) of node ids whose embeddings are returned, in order.
+    target_order: optional device int32 stable argsort of `targets` (the host has it for free when it packs a
+    step's endpoints); targets_unique: True when the caller knows that no endpoint is repeated."""
+    tix = graph.level_rows(-1, targets, 'sweep_targets')
+    return _run_sweep(conv, graph, level_nodes, tix, target_order, targets_unique)[1]
+
+
+# Speculative drop-in sweep.  The reference loop calls the model once per level with the SAME node lists every step
+# (topo_levels of the design, src/train.py:490-503) and nothing a later call passes can change what an earlier level
+# computes, so once a graph has been swept level by level with some lists, the next level-0 call runs the WHOLE sweep with
+# them (the whole-sweep kernels: batched *_self MLPs, folded gathers, one autograd node) and every level call then only
+# checks that its list is the recorded one and gathers h[targets].  A call whose list differs raises; set
+# mmft.sweep.SPECULATE = False for loops that change their level lists between steps.
+SPECULATE = True
+
+
+def _same_list(a, b):
+    return a is b or (len(a) == len(b) and (not len(a) or (a[0] == b[0] and a[-1] == b[-1] and a == b)))

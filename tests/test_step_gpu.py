@@ -280,3 +280,65 @@ def test_bench_self_launches_its_ranks(dev):
     j = json.loads(lines[0])
     assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['value'] > 0
     assert abs(j['value'] - 2 * 1 * 3 / (j['ms_per_step'] * 3 / 1e3)) / j['value'] < 1e-6      # whole-job designs / s
+
+
+def test_config_b_batch_of_eight_vs_oracle(dev):
+    """The bench's step shape - EIGHT designs merged block-diagonally in one step (per-image BatchNorm statistics, same-index
+    levels concatenated, one MSE over all endpoints) - at a reduced node count against the fp64 oracle run design by
+    design: predictions, loss and gradients (= the mean of the per-design gradients)."""
+    from mmft.fusion import mse_loss
+    from mmft.synth import synth_design
+    from mmft.train import build_models, TrainStep
+    designs = [synth_design(N=2048, L=12, tile=32, seed=800 + i, end_frac=0.25) for i in range(8)]
+    pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=23)
+    pm_state = {k: v.detach().cpu().clone() for k, v in pmodel.state_dict().items()}
+    pc_state = {k: v.detach().cpu().clone() for k, v in cnn.state_dict().items()}
+    rng = np.random.default_rng(5)
+    ids = [rng.permutation(d.num_paths)[:40].tolist() for d in designs]
+    ts = TrainStep(pmodel, cnn, designs, dev)
+    hats, ends_d, ends_h = ts.forward(ids)
+    loss = mse_loss(hats, ts.batch.arrival[ends_d.long()].squeeze(-1))
+    ts.optim.zero_grad()
+    loss.backward()
+    orc = R.OracleTrainer(pm_state, pc_state, dtype=torch.float64)
+    total, per_design = 0, {}
+    for i, d in enumerate(designs):
+        h_o, tl, _ = R.sweep_forward(orc.pm, orc.pc, d, R.design_csr(d), ids[i], update_running=False, dtype=torch.float64)
+        arr = torch.from_numpy(d.arrival_time).double()[torch.tensor(tl)].squeeze(-1)
+        total = total + torch.nn.functional.mse_loss(h_o, arr) / 8
+        per_design[i] = (h_o.detach(), [t + int(ts.batch.node_off[i]) for t in tl])
+    total.backward()
+    assert abs(float(loss) - float(total)) < 1e-4 * float(total)
+    # the merged batch orders its endpoints by level, then design: compare through the endpoint ids
+    pos = {int(e): k for k, e in enumerate(ends_h.tolist())}
+    for i, (h_o, tl) in per_design.items():
+        got = hats[[pos[t] for t in tl]]
+        assert rel_err(got, h_o) < 1e-4, i
+    for k, prm in pmodel.named_parameters():
+        if orc.pm[k].grad is not None:
+            assert rel_err(prm.grad, orc.pm[k].grad) < 2e-4, k
+    for k, prm in cnn.named_parameters():
+        assert rel_err(prm.grad, orc.pc[k].grad) < 5e-4, k
+
+
+def test_full_size_config_b_step_is_deterministic(dev):
+    """Config B as benched (8 x 65 536 nodes, 64 levels, 256 x 256 tiles, 1350 endpoints per design): two independent
+    runs of two optimizer steps from the same initialisation end bitwise equal (no float atomics on the path), and the
+    replayed HIP graph follows the eager step."""
+    from mmft.synth import synth_design
+    from mmft.train import build_models, TrainStep, GraphedTrainStep
+    designs = [synth_design(N=65536, L=64, tile=256, seed=9294 + i) for i in range(8)]
+    rng = np.random.default_rng(6)
+    batches = [[rng.permutation(d.num_paths)[:1350] for d in designs] for _ in range(2)]
+    runs = []
+    for kind in ('eager', 'eager', 'graph'):
+        pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=9294)
+        ts = TrainStep(pmodel, cnn, designs, dev)
+        stepper = GraphedTrainStep(ts, batches[0], warmup=0) if kind == 'graph' else ts
+        out = [stepper.step(ids) for ids in batches]
+        torch.cuda.synchronize()
+        runs.append((float(out[-1][0]), out[-1][1].clone(), ts.optim.flat_param.clone()))
+        del ts, stepper, pmodel, cnn
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    assert abs(runs[2][0] - runs[0][0]) < 1e-4 * abs(runs[0][0]) and rel_err(runs[2][1], runs[0][1]) < 1e-4
+    assert bool(torch.isfinite(runs[0][2]).all())
