@@ -189,6 +189,8 @@ def main():
                          'on the MFMA-bound contractions (BASELINE config B names bf16)')
     ap.add_argument('--cpu-steps', type=int, default=10)
     ap.add_argument('--no-drift', action='store_true', help='bf16: skip the fp32 replay of the schedule (MAE drift)')
+    ap.add_argument('--cone', action='store_true',
+                    help='fan-in-cone pruning inside the step (device-side mask per step; pays when --batch-paths is small)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -226,7 +228,7 @@ def main():
     pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=9294)
     pm_state = {k: v.detach().cpu().clone() for k, v in pmodel.state_dict().items()}
     pc_state = {k: v.detach().cpu().clone() for k, v in cnn.state_dict().items()}
-    ts = TrainStep(pmodel, cnn, designs, dev, world_size=world, mode=args.mode, overlap=not args.no_overlap)
+    ts = TrainStep(pmodel, cnn, designs, dev, world_size=world, mode=args.mode, overlap=not args.no_overlap, cone=args.cone)
     rng = np.random.default_rng(1234 + rank)
     log('resident on device; warm-up')
     stepper, graphed = ts, False
@@ -366,7 +368,7 @@ def main():
                             f'{args.tile}x{args.tile} tile, {args.batch_paths} endpoints/design, UNet(max), '
                             + ('fp32' if args.dtype == 'f32' else 'bf16 operands / fp32 accumulate on the MFMA-bound contractions (tensors in HBM fp32)'),
                 'designs_per_step_per_gpu': args.designs, 'nodes': args.nodes, 'levels': args.levels,
-                'tile': args.tile, 'endpoints_per_design': args.batch_paths,
+                'tile': args.tile, 'endpoints_per_design': args.batch_paths, 'cone_pruning': bool(args.cone),
                 'parallelism': f'dp{world} (designs sharded, one all-reduce of the flat gradient per step)',
                 'launch': ('one HIP graph replay per step' + ('' if world == 1 else ' (forward+backward) + eager all-reduce + Adam'))
                 if graphed else 'eager launches',

@@ -102,7 +102,12 @@ int mmft_mlp2_first_layer_grads(const float* g, long long ldg, const float* hid,
 int mmft_mlp2_rows(const float* x1, long long ldx1, const int* rows, int n, const float* w1, long long ldw1,
                    const float* b1, const float* w2, long long ldw2, const float* b2, int weights_kmajor,
                    const float* mask, long long ldmask, float* hid_out, long long ldhid, float* out,
-                   long long ldout, int add_act, int relu_out, int K1, int HD, int D2, int device, void* stream);
+                   long long ldout, int add_act, int relu_out, int K1, int HD, int D2, const unsigned char* active,
+                   int device, void* stream);
+/* active (optional, may be NULL; also on mmft_pair_fwd_gather / mmft_level_bwd_pull): one flag per node marking the
+ * transitive fan-in cone of the step's sampled endpoints (mmft_fanin_cone_step).  Rows outside it are skipped - a tile of
+ * 32 such rows exits at once - and their outputs are left untouched; the reverse pull does not read cell consumers outside
+ * the cone.  The caller zero-fills G / DA for such a step (rows outside the cone must read as zero gradients). */
 /* out[c] (+)= sum_r g[idx[r]][c]   (bias gradients); workspace >= mmft_colsum_workspace_bytes */
 long long mmft_colsum_workspace_bytes(int rows, int cols);
 int mmft_colsum(const float* g, const int* idx, long long ld, int rows, int cols, float* out, int accumulate,
@@ -180,8 +185,8 @@ int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows,
                         const int* out_net_indptr, const int* out_net_indices, const float* out_net_weight,
                         const int* out_cell_indptr, const int* out_cell_indices,
                         const float* A, const float* LSE, const float* DA, int relu, const unsigned char* own_mask,
-                        const int* heavy_rows, int nheavy, int heavy_thresh, long long alg_bytes, int device,
-                        void* stream);
+                        const int* heavy_rows, int nheavy, int heavy_thresh, const unsigned char* active,
+                        long long alg_bytes, int device, void* stream);
 /* heavy_rows (optional, nheavy of them): exactly the rows of this level whose out-degree (net + cell) exceeds
  * heavy_thresh.  Each is reduced by a whole workgroup - eight thread groups stride over its out-edges, partial sums
  * combined through LDS in a fixed order (deterministic) - instead of one 32-lane group walking hundreds of dependent
@@ -196,8 +201,8 @@ int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows,
 int mmft_pair_fwd_gather(float* h, const float* pre, long long ld, int D, const int* in_net_indptr,
                          const int* in_net_indices, const int* in_cell_indptr, const int* in_cell_indices, int net_row0,
                          int n_net, const int* cell_rows, int cell_row0, int n_cell, float* A, float* LSE, long long lda,
-                         int relu, const int* heavy_rows, int nheavy, int heavy_thresh, long long alg_bytes, int device,
-                         void* stream);
+                         int relu, const int* heavy_rows, int nheavy, int heavy_thresh, const unsigned char* active,
+                         long long alg_bytes, int device, void* stream);
 /* own_mask (may be NULL): per-node flag telling whether G[v] already holds a gradient of its own (a sampled endpoint,
  * src/model.py:213); rows without the flag start from zero, so G needs no 4*N*D-byte fill per step.
  * mmft_target_rows_begin zeroes the G rows of the endpoints idx[0..n) and sets their flags (the scatter-add of the
@@ -205,6 +210,8 @@ int mmft_pair_fwd_gather(float* h, const float* pre, long long ld, int D, const 
 int mmft_target_rows_begin(float* G, long long ld, const int* idx, int n, int D, unsigned char* flags, int device,
                            void* stream);
 int mmft_target_rows_end(const int* idx, int n, unsigned char* flags, int device, void* stream);
+/* flags[idx[i]] = value for i < n (seeds the fan-in-cone mask with the step's endpoints) */
+int mmft_mark_rows(const int* idx, int n, unsigned char* flags, int value, int device, void* stream);
 /* Persistent forward sweep: ONE launch for levels 1..L-1 of a mini-batch (the L per-level PathConv.forward calls of
  * src/train.py:490-511).  h must hold the *_self MLP outputs of every node (level 0 already activated); levels
  * are separated by an in-kernel grid barrier (agent-scope release/acquire, bounded spin).  level_ptr[L+1] /

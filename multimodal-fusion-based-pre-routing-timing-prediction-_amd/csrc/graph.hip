@@ -90,7 +90,10 @@ __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
     int D, const int* __restrict__ on_ptr, const int* __restrict__ on_idx, const float* __restrict__ on_w,
     const int* __restrict__ oc_ptr, const int* __restrict__ oc_idx, const float* __restrict__ A,
     const float* __restrict__ LSE, const float* __restrict__ DA, int relu, const unsigned char* __restrict__ own,
-    const int* __restrict__ heavy, int nheavy, int light_blocks, int heavy_thresh) {
+    const int* __restrict__ heavy, int nheavy, int light_blocks, int heavy_thresh,
+    const unsigned char* __restrict__ active) {
+  // active (optional): per-node flags of the fan-in cone of this step's endpoints; rows outside it are skipped (their G
+  // stays at the zero the caller filled in) and cell consumers outside it are not read (their A / LSE rows are stale).
   // Heavy rows (drivers of clock / reset-like nets, SRAM pins: out-degree in the hundreds) get a whole workgroup each:
   // its thread groups stride over the row's out-edges and the partial sums are combined through LDS in a fixed order
   // (bitwise reproducible).  One 32-lane group walking such a row in series is what set the duration of a level's
@@ -101,6 +104,7 @@ __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
     const int tg = threadIdx.x / groups, c = (threadIdx.x - tg * groups) * 4;
     for (int hi = (int)blockIdx.x - light_blocks; hi < nheavy; hi += (int)gridDim.x - light_blocks) {
       const int v = heavy[hi];
+      if (active && !active[v]) continue;                // block-uniform
       const long long off = (long long)v * ld + c;
       const f32x4 hv = ld4(h + off);
       if (tg < act) {
@@ -120,6 +124,7 @@ __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
         for (; e < e1; e += act) g += ld4(G + (long long)on_idx[e] * ld + c) * on_w[e];
         const int c1 = oc_ptr[v + 1];
         for (e = oc_ptr[v] + tg; e < c1; e += act) {
+          if (active && !active[oc_idx[e]]) continue;
           long long wo = (long long)oc_idx[e] * ld + c;
           f32x4 da = ld4(DA + wo), a = ld4(A + wo), l = ld4(LSE + wo);
 #pragma unroll
@@ -147,6 +152,7 @@ __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
     int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
     int v = rows ? rows[i] : row0 + i;
     if (heavy && (on_ptr[v + 1] - on_ptr[v]) + (oc_ptr[v + 1] - oc_ptr[v]) > heavy_thresh) continue;
+    if (active && !active[v]) continue;
     long long off = (long long)v * ld + c;
     // both edge ranges are requested up front: a node has net OR cell consumers, and the second pointer pair would
     // otherwise start its own dependent chain (pointer -> index -> row) only after the first loop
@@ -172,17 +178,21 @@ __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
     e = c0;
     e1 = c1;
     for (; e + 2 <= e1; e += 2) {
-      long long o0 = (long long)oc_idx[e] * ld + c, o1 = (long long)oc_idx[e + 1] * ld + c;
+      const int w0 = oc_idx[e], w1 = oc_idx[e + 1];
+      long long o0 = (long long)w0 * ld + c, o1 = (long long)w1 * ld + c;
       f32x4 da0 = ld4(DA + o0), a0 = ld4(A + o0), l0 = ld4(LSE + o0);
       f32x4 da1 = ld4(DA + o1), a1 = ld4(A + o1), l1 = ld4(LSE + o1);
+      const bool k0 = !active || active[w0], k1 = !active || active[w1];    // outside the cone: contributes exactly zero
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        g[j] += da0[j] * expf(hv[j] - l0[j]) * (1.0f + hv[j] - a0[j]);
-        g[j] += da1[j] * expf(hv[j] - l1[j]) * (1.0f + hv[j] - a1[j]);
+        g[j] += k0 ? da0[j] * expf(hv[j] - l0[j]) * (1.0f + hv[j] - a0[j]) : 0.f;
+        g[j] += k1 ? da1[j] * expf(hv[j] - l1[j]) * (1.0f + hv[j] - a1[j]) : 0.f;
       }
     }
     for (; e < e1; ++e) {
-      long long wo = (long long)oc_idx[e] * ld + c;
+      const int w = oc_idx[e];
+      if (active && !active[w]) continue;
+      long long wo = (long long)w * ld + c;
       f32x4 da = ld4(DA + wo), a = ld4(A + wo), l = ld4(LSE + wo);
 #pragma unroll
       for (int j = 0; j < 4; ++j) g[j] += da[j] * expf(hv[j] - l[j]) * (1.0f + hv[j] - a[j]);
@@ -246,7 +256,8 @@ __global__ void __launch_bounds__(256) pair_fwd_gather_kernel(
     float* __restrict__ h, const float* __restrict__ PRE, long long ld, int D, const int* __restrict__ in_ptr,
     const int* __restrict__ in_idx, const int* __restrict__ ic_ptr, const int* __restrict__ ic_idx, int net_row0, int n_net,
     const int* __restrict__ rows, int cell_row0, int n_cell, float* __restrict__ A, float* __restrict__ LSE, long long lda,
-    int relu, const int* __restrict__ heavy, int nheavy, int light_blocks, int heavy_thresh) {
+    int relu, const int* __restrict__ heavy, int nheavy, int light_blocks, int heavy_thresh,
+    const unsigned char* __restrict__ active) {
   __shared__ f32x4 pm[8][64], ps[8][64], pa[8][64];
   const int groups = D >> 2;
   if ((int)blockIdx.x >= light_blocks) {
@@ -254,6 +265,7 @@ __global__ void __launch_bounds__(256) pair_fwd_gather_kernel(
     const int tg = threadIdx.x / groups, c = (threadIdx.x - tg * groups) * 4;
     for (int hi = (int)blockIdx.x - light_blocks; hi < nheavy; hi += (int)gridDim.x - light_blocks) {
       const int v = heavy[hi];
+      if (active && !active[v]) continue;                    // block-uniform: outside this step's fan-in cone
       const int e0 = ic_ptr[v], e1 = ic_ptr[v + 1];
       if (tg < act) {
         SoftAcc sa;
@@ -297,6 +309,7 @@ __global__ void __launch_bounds__(256) pair_fwd_gather_kernel(
     int i = (int)(t / groups), c = (int)(t - (long long)i * groups) * 4;
     if (i < n_net) {                                         // part A
       const int u = net_row0 + i;
+      if (active && !active[u]) continue;
       st4(h + (long long)u * ld + c, net_node_value(h, PRE, ld, u, c, in_ptr, in_idx, relu));
       continue;
     }
@@ -304,6 +317,7 @@ __global__ void __launch_bounds__(256) pair_fwd_gather_kernel(
     const int v = rows ? rows[i] : cell_row0 + i;
     const int e0 = ic_ptr[v], e1 = ic_ptr[v + 1];
     if (e1 - e0 > heavy_thresh && heavy) continue;
+    if (active && !active[v]) continue;
     SoftAcc sa;
     sa.init();
     for (int e = e0; e < e1; ++e) {
@@ -676,7 +690,7 @@ int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows,
                         const int* out_net_indptr, const int* out_net_indices, const float* out_net_weight,
                         const int* out_cell_indptr, const int* out_cell_indices, const float* A, const float* LSE,
                         const float* DA, int relu, const unsigned char* own_mask, const int* heavy_rows, int nheavy,
-                        int heavy_thresh, long long alg_bytes, int device, void* stream) {
+                        int heavy_thresh, const unsigned char* active, long long alg_bytes, int device, void* stream) {
   CHECK_ROWS("level_bwd_pull");
   MMFT_REQUIRE(nheavy >= 0 && (nheavy == 0 || heavy_rows) && heavy_thresh >= 0, "level_bwd_pull: heavy row list");
   MMFT_REQUIRE(nheavy == 0 || (D <= 256 && 256 % (D / 4) == 0), "level_bwd_pull: heavy rows need D / 4 to divide 256");
@@ -692,15 +706,15 @@ int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows,
   MMFT_LAUNCH("level_bwd_pull_kernel", 0.0, alg_bytes > 0 ? (double)alg_bytes : 3.0 * 4.0 * n * D, level_bwd_pull_kernel,
               dim3(light + hb), dim3(256), (hipStream_t)stream, G, h, ld, rows, row0, n, D, out_net_indptr,
               out_net_indices, out_net_weight, out_cell_indptr, out_cell_indices, A, LSE, DA, relu, own_mask,
-              nheavy ? heavy_rows : nullptr, nheavy, light, heavy_thresh);
+              nheavy ? heavy_rows : nullptr, nheavy, light, heavy_thresh, active);
   return check_launch("level_bwd_pull");
 }
 
 int mmft_pair_fwd_gather(float* h, const float* pre, long long ld, int D, const int* in_net_indptr,
                          const int* in_net_indices, const int* in_cell_indptr, const int* in_cell_indices, int net_row0,
                          int n_net, const int* cell_rows, int cell_row0, int n_cell, float* A, float* LSE, long long lda,
-                         int relu, const int* heavy_rows, int nheavy, int heavy_thresh, long long alg_bytes, int device,
-                         void* stream) {
+                         int relu, const int* heavy_rows, int nheavy, int heavy_thresh, const unsigned char* active,
+                         long long alg_bytes, int device, void* stream) {
   const int n = n_net + n_cell;
   CHECK_ROWS("pair_fwd_gather");
   MMFT_REQUIRE(n_net >= 0 && n_cell >= 0 && net_row0 >= 0 && cell_row0 >= 0, "pair_fwd_gather: negative row count / offset");
@@ -717,7 +731,7 @@ int mmft_pair_fwd_gather(float* h, const float* pre, long long ld, int D, const 
   MMFT_LAUNCH("pair_fwd_gather_kernel", 0.0, alg_bytes > 0 ? (double)alg_bytes : 3.0 * 4.0 * n * D, pair_fwd_gather_kernel,
               dim3(light + hb), dim3(256), (hipStream_t)stream, h, pre, ld, D, in_net_indptr, in_net_indices, in_cell_indptr,
               in_cell_indices, net_row0, n_net, cell_rows, cell_row0, n_cell, A, LSE, lda, relu,
-              nheavy ? heavy_rows : nullptr, nheavy, light, heavy_thresh);
+              nheavy ? heavy_rows : nullptr, nheavy, light, heavy_thresh, active);
   return check_launch("pair_fwd_gather");
 }
 
@@ -738,6 +752,16 @@ int mmft_target_rows_end(const int* idx, int n, unsigned char* flags, int device
   DeviceGuard dg(device);
   hipLaunchKernelGGL(target_rows_kernel, dim3(node_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, nullptr, 0, idx, n, 4, flags, 0);
   return check_launch("target_rows_end");
+}
+
+int mmft_mark_rows(const int* idx, int n, unsigned char* flags, int value, int device, void* stream) {
+  MMFT_REQUIRE(n >= 0, "mark_rows: negative count");
+  if (n == 0) return MMFT_OK;
+  MMFT_REQUIRE(idx && flags, "mark_rows: null pointer");
+  DeviceGuard dg(device);
+  hipLaunchKernelGGL(target_rows_kernel, dim3(node_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, nullptr, 0, idx, n, 4, flags,
+                     value ? 1 : 0);
+  return check_launch("mark_rows");
 }
 
 int mmft_gather_rows(const float* src, long long lds, const int* idx, int n, int D, float* dst, long long ldd,

@@ -34,6 +34,13 @@ __global__ void __launch_bounds__(NW * 64, 1) mlp2_rows_kernel(Mlp2Args a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * M2_BM;
+  auto live_row = [&](int r) -> bool { return m0 + r < a.n && (!a.active || a.active[a.rows[m0 + r]]); };
+  if (a.active) {
+    // a tile without a single row inside the step's fan-in cone has nothing to do
+    int any = 0;
+    if (tid < M2_BM) any = live_row(tid) ? 1 : 0;
+    if (!__syncthreads_or(any)) return;
+  }
 
   // ---- every global load of the kernel is issued here: both weight panels and the gathered x1 rows
   WPanel<KM, M2_HD, M2_K1 / M2_BK, NT> p1;
@@ -45,7 +52,7 @@ __global__ void __launch_bounds__(NW * 64, 1) mlp2_rows_kernel(Mlp2Args a) {
     int g = tid + i * NT;
     int r = g / (M2_K1 / 4), k4 = g % (M2_K1 / 4);
     xr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (m0 + r < a.n) xr[i] = *reinterpret_cast<const f32x4*>(a.x1 + (long long)a.rows[m0 + r] * a.ldx1 + k4 * 4);
+    if (live_row(r)) xr[i] = *reinterpret_cast<const f32x4*>(a.x1 + (long long)a.rows[m0 + r] * a.ldx1 + k4 * 4);
   }
   p2.load(a.w2, a.ldw2, tid);
 #pragma unroll
@@ -71,7 +78,7 @@ __global__ void __launch_bounds__(NW * 64, 1) mlp2_rows_kernel(Mlp2Args a) {
       int m = i * 16 + (lane & 15);
       int nn = wave * (HC * 16) + j * 16 + (lane >> 4) * 4;
       f32x4 v = acc1[i][j];
-      bool live = m0 + m < a.n;
+      bool live = live_row(m);
       long long row = live ? (long long)a.rows[m0 + m] : 0;
       if (a.mask) {
         f32x4 mk = {0.f, 0.f, 0.f, 0.f};
@@ -104,7 +111,7 @@ __global__ void __launch_bounds__(NW * 64, 1) mlp2_rows_kernel(Mlp2Args a) {
 #pragma unroll
     for (int j = 0; j < OC; ++j) {
       int m = i * 16 + (lane & 15);
-      if (m0 + m >= a.n) continue;
+      if (!live_row(m)) continue;
       int nn = wave * (OC * 16) + j * 16 + (lane >> 4) * 4;
       float* q = a.out + (long long)a.rows[m0 + m] * a.ldout + nn;
       f32x4 v = acc2[i][j];
@@ -127,8 +134,8 @@ using namespace mmft;
 extern "C" int mmft_mlp2_rows(const float* x1, long long ldx1, const int* rows, int n, const float* w1, long long ldw1,
                               const float* b1, const float* w2, long long ldw2, const float* b2, int weights_kmajor,
                               const float* mask, long long ldmask, float* hid_out, long long ldhid, float* out,
-                              long long ldout, int add_act, int relu_out, int K1, int HD, int D2, int device,
-                              void* stream) {
+                              long long ldout, int add_act, int relu_out, int K1, int HD, int D2,
+                              const unsigned char* active, int device, void* stream) {
   MMFT_REQUIRE(x1 && rows && w1 && w2 && out, "mlp2_rows: null pointer");
   if (K1 != M2_K1 || HD != M2_HD || D2 != M2_D2) {
     set_error("mlp2_rows: only %d -> %d -> %d is fused (got %d -> %d -> %d)", M2_K1, M2_HD, M2_D2, K1, HD, D2);
@@ -144,7 +151,7 @@ extern "C" int mmft_mlp2_rows(const float* x1, long long ldx1, const int* rows, 
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
   hipStream_t st = (hipStream_t)stream;
-  Mlp2Args a{x1, ldx1, rows, n, w1, ldw1, b1, w2, ldw2, b2, mask, ldmask, hid_out, ldhid, out, ldout, add_act, relu_out};
+  Mlp2Args a{x1, ldx1, rows, n, w1, ldw1, b1, w2, ldw2, b2, mask, ldmask, hid_out, ldhid, out, ldout, add_act, relu_out, active};
   const double fl = 2.0 * n * ((double)K1 * HD + (double)HD * D2), by = 4.0 * n * ((double)K1 + 2.0 * HD + 2.0 * D2);
   static int nw = -1;
   if (nw < 0) {

@@ -26,6 +26,7 @@ struct Mlp2Args {
   long long ldout;
   int add_act;   // 1: out = act(out_old + acc + b2), 0: out = acc + b2
   int relu_out;
+  const unsigned char* active;   // optional per-node flags (fan-in cone of the step): rows outside it are not computed
 };
 
 // Weight panels are read from L2 ONCE per workgroup, at kernel entry, with every 16-byte load of both layers in

@@ -171,7 +171,8 @@ def mlp2_fusable(K1, HD, D2):
     return (K1, HD, D2) == (128, 256, 128)
 
 
-def mlp2_rows(x1, rows, w1, b1, w2, b2, out, kmajor=False, mask=None, hid_out=None, add_act=False, relu_out=False):
+def mlp2_rows(x1, rows, w1, b1, w2, b2, out, kmajor=False, mask=None, hid_out=None, add_act=False, relu_out=False,
+              active=None):
     """Fused Linear-ReLU-Linear over the gathered rows `rows` (see mmft_mlp2_rows in include/mmft.h)."""
     _rows2d(x1, 'x1'); _rows2d(w1, 'w1'); _rows2d(w2, 'w2'); _rows2d(out, 'out'); _idx(rows, 'rows')
     if kmajor:
@@ -193,8 +194,17 @@ def mlp2_rows(x1, rows, w1, b1, w2, b2, out, kmajor=False, mask=None, hid_out=No
     lib.call('mmft_mlp2_rows', x1, x1.stride(0), rows, rows.numel(), w1, w1.stride(0), b1, w2, w2.stride(0), b2,
              int(kmajor), mask, mask.stride(0) if mask is not None else 0, hid_out,
              hid_out.stride(0) if hid_out is not None else 0, out, out.stride(0), int(add_act), int(relu_out),
-             K1, HD, D2, dev, st)
+             K1, HD, D2, _active(active, x1.shape[0]), dev, st)
     return out
+
+
+def _active(active, N):
+    if active is None:
+        return None
+    _chk(active, 'active', torch.uint8)
+    if active.numel() != N or not active.is_contiguous():
+        raise ValueError('active: one uint8 flag per node expected')
+    return active
 
 
 def sweep_fwd_persistent(h, A, LSE, HN, in_net, in_cell, level_ptr, level_rows, L, w1, b1, w2, b2, relu, max_rows,
@@ -339,7 +349,7 @@ def target_rows_end(idx, flags):
 
 
 def level_bwd_pull(G, h, rows, out_net, out_net_w, out_cell, A, LSE, DA, relu=True, alg_bytes=0, own=None, heavy=None,
-                   heavy_thresh=PAIR_HEAVY_OUT):
+                   heavy_thresh=PAIR_HEAVY_OUT, active=None):
     for t, nm in ((G, 'G'), (h, 'h'), (A, 'A'), (LSE, 'LSE'), (DA, 'DA')):
         _rows2d(t, nm)
         if t.shape != h.shape or t.stride(0) != h.stride(0):
@@ -359,14 +369,14 @@ def level_bwd_pull(G, h, rows, out_net, out_net_w, out_cell, A, LSE, DA, relu=Tr
         _idx(heavy, 'heavy')
     lib.call('mmft_level_bwd_pull', G, h, h.stride(0), rt, row0, n, h.shape[1], out_net[0], out_net[1], out_net_w,
              out_cell[0], out_cell[1], A, LSE, DA, int(relu), own, heavy, heavy.numel() if heavy is not None else 0,
-             int(heavy_thresh), int(alg_bytes), dev, st)
+             int(heavy_thresh), _active(active, N), int(alg_bytes), dev, st)
     return G
 
 
 
 
 def pair_fwd_gather(h, pre, in_net, in_cell, net_range, cell_rows, A, LSE, relu=True, heavy=None, heavy_thresh=PAIR_HEAVY_IN,
-                    alg_bytes=0):
+                    alg_bytes=0, active=None):
     """Folded forward gather of one (net level, cell level) pair: see mmft_pair_fwd_gather in include/mmft.h.
     net_range = (row0, n); cell_rows = int32 tensor | (row0, n) | None (no cell level)."""
     _rows2d(h, 'h'); _rows2d(pre, 'pre')
@@ -387,7 +397,7 @@ def pair_fwd_gather(h, pre, in_net, in_cell, net_range, cell_rows, A, LSE, relu=
     dev, st = lib.stream_args(h)
     lib.call('mmft_pair_fwd_gather', h, pre, h.stride(0), h.shape[1], in_net[0], in_net[1], in_cell[0], in_cell[1], nrow0, nn,
              ct, crow0, nc, A if nc else None, LSE if nc else None, A.stride(0) if nc else h.stride(0), int(relu), heavy,
-             heavy.numel() if heavy is not None else 0, int(heavy_thresh), int(alg_bytes), dev, st)
+             heavy.numel() if heavy is not None else 0, int(heavy_thresh), _active(active, N), int(alg_bytes), dev, st)
 
 
 ATTN_SLOPE = 0.01          # F.leaky_relu default (src/model.py:136)

@@ -84,6 +84,25 @@ def fanin_cone(in_csrs, level_nodes, targets):
     return out
 
 
+def cone_mask(in_csrs, level_nodes, targets, out=None):
+    """uint8[N] on the device: 1 for every node in the transitive fan-in of `targets` (the endpoints included).  No host
+    synchronisation and only fixed-size launches (one per level), so it can run inside a captured step: the mask is what
+    the sweep kernels take as `active`."""
+    p = _csr_pair(in_csrs)
+    ops._chk(targets, 'targets', torch.int32)
+    n_nodes = p[0].numel() - 1
+    mark = out if (out is not None and out.numel() == n_nodes and out.device == targets.device) else \
+        torch.empty(n_nodes, dtype=torch.uint8, device=targets.device)
+    mark.zero_()
+    dev, st = lib.stream_args(mark)
+    if targets.numel():
+        lib.call('mmft_mark_rows', targets, targets.numel(), mark, 1, dev, st)
+    for nodes in reversed(list(level_nodes)[1:]):
+        idx, row0, n = ops._rowspec(nodes, n_nodes, 'level_nodes')
+        lib.call('mmft_fanin_cone_step', idx, row0, n, p[0], p[1], p[2], p[3], mark, dev, st)
+    return mark
+
+
 def trace_critical_paths(in_csrs, level, endpoints, stop=None, maxlen=None):
     """paths int32[P, maxlen] (-1 padded, endpoint first) and lens int32[P]; `stop`: optional uint8 flags per node."""
     p = _csr_pair(in_csrs)

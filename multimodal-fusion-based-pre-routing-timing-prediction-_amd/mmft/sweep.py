@@ -59,6 +59,7 @@ class SweepState:
         self.fold = None                    # static facts for the folded level kernels (PinGraph.fold_schedule)
         self.PRE = None
         self.attn = None                    # attention branch (flag_attn): dict(key, c12, alpha, dcp, o2i)
+        self.active = None                  # uint8 per node: fan-in cone of the step's endpoints (None: every node)
         self.spec_lists = None              # speculative drop-in sweep: the level lists it ran with, its token, target rows
         self.spec_token = None
         self.spec_tix = []
@@ -68,7 +69,9 @@ class SweepState:
     def _buf(self, name, width):
         b = self._bufs.get(name)
         if b is None:
-            b = torch.empty((self.N, width), dtype=torch.float32, device=self.h.device)
+            # zeros, not empty: with fan-in-cone pruning rows outside the cone are never written, yet batched GEMMs read
+            # them next to zero gradients - they must hold finite values
+            b = torch.zeros((self.N, width), dtype=torch.float32, device=self.h.device)
             self._bufs[name] = b
         return b
 
@@ -131,7 +134,7 @@ def _pull_bwd(st, g, rows, own=None, alg_bytes=0, heavy=None):
                                 a['alpha'], st.DA, relu=st.relu, own=own)
     else:
         ops.level_bwd_pull(st.G, st.h, rows, g.csr('out', 'net'), g.out_net_weight(), g.csr('out', 'cell'),
-                           st.A, st.LSE, st.DA, relu=st.relu, alg_bytes=alg_bytes, own=own, heavy=heavy)
+                           st.A, st.LSE, st.DA, relu=st.relu, alg_bytes=alg_bytes, own=own, heavy=heavy, active=st.active)
 
 
 def _attn_scores_bwd(st, g, rows):
@@ -175,7 +178,7 @@ def _cell_neigh_fwd(st, rows, w1g, b1g, w2g, b2g, act):
     """h[rows] = act(h[rows] + fc_cell_neigh(A[rows])), HN[rows] saved: one fused launch when the widths allow."""
     if ops.mlp2_fusable(st.D, st.Hd, st.D):
         ops.mlp2_rows(st.A, rows, w1g, b1g, w2g, b2g, st.h, kmajor=False, hid_out=st.HN, add_act=True,
-                      relu_out=(act == ops.ACT_RELU))
+                      relu_out=(act == ops.ACT_RELU), active=st.active)
     else:
         ops.linear_fwd(st.A, w1g, b1g, y=st.HN, xidx=rows, yidx=rows, act=ops.ACT_RELU)
         ops.linear_fwd(st.HN, w2g, b2g, y=st.h, xidx=rows, yidx=rows, epi=ops.EPI_ADD_ACT, act=act)
@@ -190,7 +193,7 @@ def _cell_neigh_bwd(st, rows, w1g, w2g, keep_dhn=False):
             if st.DHN is None:
                 st.DHN = st._buf('DHN', st.Hd)
             dhn_out = st.DHN
-        ops.mlp2_rows(st.G, rows, w2g, None, w1g, None, st.DA, kmajor=True, mask=st.HN, hid_out=dhn_out)
+        ops.mlp2_rows(st.G, rows, w2g, None, w1g, None, st.DA, kmajor=True, mask=st.HN, hid_out=dhn_out, active=st.active)
     else:
         dhn = ops.linear_dgrad(st.G, w2g, gidx=rows, mask=st.HN, maskidx=rows)
         ops.linear_dgrad(dhn, w1g, dx=st.DA, dxidx=rows)
@@ -356,10 +359,20 @@ def level_forward(conv, graph, cur_nodes, targets, level_id):
         if level_id != st.next_level:
             raise RuntimeError(f'PathConv: levels must arrive in increasing order (got {level_id}, expected {st.next_level})')
         st.next_level = level_id + 1
-        if level_id >= len(st.spec_lists) or torch.is_tensor(cur_nodes) or not _same_list(cur_nodes, st.spec_lists[level_id]):
+        mismatch = level_id >= len(st.spec_lists) or torch.is_tensor(cur_nodes) or not _same_list(cur_nodes, st.spec_lists[level_id])
+        if mismatch and not st.need_grad:
+            # inference with other lists than last time (e.g. validate() after a truncated sweep): the levels below this
+            # one were computed from identical lists, so the sweep simply continues level by level from here
+            graph.__dict__['_spec_lists'] = None
+            nst = SweepState(graph, conv)
+            nst.next_level = level_id
+            graph._sweep = st = nst
+            spec_active = False
+        elif mismatch:
             raise RuntimeError(f'PathConv: level {level_id} arrived with a node list that differs from the one this graph was '
                                f'swept with before - the speculative whole-sweep of the level-0 call used the recorded lists. '
                                f'Set mmft.sweep.SPECULATE = False for loops whose level lists change between steps.')
+    if spec_active:
         tix = graph.level_rows(level_id, targets, 'targets')
         if not tix.numel():
             return st.h.new_zeros((0, st.D))
@@ -497,7 +510,7 @@ class SweepFn(torch.autograd.Function):
                 if has_cell:
                     crow = fold[level_id]['range'] or level_rows[level_id]
                 ops.pair_fwd_gather(st.h, st.PRE, in_net, in_cell, fold[net_l]['range'] or (0, 0), crow, st.A, st.LSE,
-                                    relu=st.relu, heavy=fold[level_id]['heavy_in'] if has_cell else None,
+                                    relu=st.relu, heavy=fold[level_id]['heavy_in'] if has_cell else None, active=st.active,
                                     alg_bytes=(meta_n['bytes_mean'] if meta_n else 0) + (meta_c['bytes_softmax'] if (meta_c and has_cell) else 0))
                 if has_cell:
                     _cell_neigh_fwd(st, level_rows[level_id], w1g, b1g, w2g, b2g, act)
@@ -530,7 +543,8 @@ class SweepFn(torch.autograd.Function):
         # schedule of the graph: then every row a pull reads was rewritten earlier in this reverse sweep.  With a
         # partial schedule (fan-in cone, truncated lists) consumers outside it keep rows from an earlier step - or
         # uninitialised memory - so both buffers are zero-filled and the own-gradient flags are not used.
-        fast = st.complete
+        # fan-in-cone pruning: rows outside the cone are skipped, so G / DA are zero-filled (their rows must read as zero)
+        fast = st.complete and st.active is None
         st.begin_backward(zero_da=not fast, zero_g=not fast)
         own = st.tflag if fast else None
         tix = ctx.tix
@@ -553,10 +567,11 @@ class SweepFn(torch.autograd.Function):
             _pull_bwd(st, g, spec, own=own, alg_bytes=meta['bytes_pull'] if meta else 0,
                       heavy=meta['heavy_out'] if meta else None)
             if level_id % 2 == 0 and level_id > 0:
-                _cell_neigh_bwd(st, rows, w1g, w2g, keep_dhn=True)
+                # (cone pruning: the hidden gradients of skipped rows would be stale - recompute them from G = 0 instead)
+                _cell_neigh_bwd(st, rows, w1g, w2g, keep_dhn=st.active is None)
                 if ctx.has_c12:
                     _attn_scores_bwd(st, g, spec)
-        grads = _batched_param_grads(st, P, dhn_ready=True) if ctx.nparams else []
+        grads = _batched_param_grads(st, P, dhn_ready=st.active is None) if ctx.nparams else []
         dc = None
         if ctx.has_c12:
             rc2 = st.row_sets[2]
@@ -580,7 +595,7 @@ class TargetGatherFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         st = ctx.state
-        fast = st.complete
+        fast = st.complete and st.active is None
         st.begin_backward(zero_da=not fast, zero_g=not fast)
         if fast:
             ops.target_rows_begin(st.G, ctx.tix, st.tflag)
@@ -588,10 +603,11 @@ class TargetGatherFn(torch.autograd.Function):
         return st.h.new_zeros(1), None, None, None
 
 
-def _run_sweep(conv, graph, level_nodes, tix, target_order=None, targets_unique=None):
+def _run_sweep(conv, graph, level_nodes, tix, target_order=None, targets_unique=None, active=None):
     """Build the sweep state for the given level lists and run SweepFn (tix None: deferred per-level target gathers)."""
     st = SweepState(graph, conv)
     graph._sweep = st
+    st.active = active
     st.complete = graph.level_set_is_complete(level_nodes)
     st.fold = graph.fold_schedule(level_nodes) if (FOLD_LEVELS and st.complete and not getattr(conv, 'flag_attn', False)) else None
     st.target_order, st.targets_unique = target_order, targets_unique
@@ -613,13 +629,28 @@ def _run_sweep(conv, graph, level_nodes, tix, target_order=None, targets_unique=
         return st, SweepFn.apply(st, level_rows, tix, c12)
 
 
-def sweep_forward_all(conv, graph, level_nodes, targets, target_order=None, targets_unique=None):
+def sweep_forward_all(conv, graph, level_nodes, targets, target_order=None, targets_unique=None, cone=False):
     """All levels of one sweep in one call. level_nodes: list (per level) of python int lists or device int32
     tensors; targets: device int32 tensor (or list) of node ids whose embeddings are returned, in order.
     target_order: optional device int32 stable argsort of `targets` (the host has it for free when it packs a
-    step's endpoints); targets_unique: True when the caller knows that no endpoint is repeated."""
+    step's endpoints); targets_unique: True when the caller knows that no endpoint is repeated.
+    cone=True: fan-in-cone pruning (the reference carries the idea unused, src/MyDataloader.py:4-59) -
+    the level kernels skip every node that cannot influence `targets`.  The cone is a per-node flag array built ON THE
+    DEVICE by L - 1 fixed-size launches (mmft_fanin_cone_step), the launches of the sweep keep their full grids and
+    skip flagged-off rows, so a captured HIP graph of the step stays valid while the sampled endpoints - and with them
+    the cone - change from replay to replay."""
     tix = graph.level_rows(-1, targets, 'sweep_targets')
-    return _run_sweep(conv, graph, level_nodes, tix, target_order, targets_unique)[1]
+    active = None
+    if cone:
+        from . import prep
+        specs = []
+        for l, nodes in enumerate(level_nodes):
+            meta = graph.level_meta(l, nodes) if not torch.is_tensor(nodes) else None
+            specs.append(meta['range'] if (meta and meta['range']) else graph.level_rows(l, nodes, 'nodes'))
+        active = prep.cone_mask([graph.csr('in', 'net'), graph.csr('in', 'cell')], specs, tix,
+                                out=graph.__dict__.get('_cone_mask'))
+        graph.__dict__['_cone_mask'] = active
+    return _run_sweep(conv, graph, level_nodes, tix, target_order, targets_unique, active)[1]
 
 
 # Speculative drop-in sweep.  The reference loop calls the model once per level with the SAME node lists every step

@@ -167,13 +167,16 @@ class DesignBatch:
 
 class TrainStep:
     def __init__(self, pmodel, cnn, designs, device, lr=1e-3, weight_decay=0.0, fused_optimizer=True, world_size=1,
-                 mode='sweep', overlap=True, with_optimizer=True, task='reg'):
+                 mode='sweep', overlap=True, with_optimizer=True, task='reg', cone=False):
         """mode='dropin': per-level model() calls exactly as src/train.py:490-511;
         mode='sweep': PathModel.forward_sweep, same arithmetic with level-invariant work hoisted.
         task='reg': MSE on the arrival time (nlabels = 1); task='cls': CrossEntropy on ndata['label'] with a
         nlabels-wide head (src/train.py:32,513-522; src/options.py:32,49)."""
         assert mode in ('dropin', 'sweep') and task in ('reg', 'cls')
         self.mode, self.task = mode, task
+        # cone=True (sweep mode): the level kernels skip every node outside the fan-in cone of the step's endpoints
+        # (device-side mask per step; pays when few endpoints of a large design are sampled, see sweep_forward_all)
+        self.cone = bool(cone) and mode == 'sweep'
         self.overlap = overlap and mode == 'sweep'
         self.side = torch.cuda.Stream(device=device) if self.overlap else None
         self.pmodel, self.cnn = pmodel, cnn
@@ -221,9 +224,10 @@ class TrainStep:
                     self.side.wait_stream(cur)
                     with torch.cuda.stream(self.side):
                         h_gnn = _sweep.sweep_forward_all(self.pmodel.gnn, g, b.level_nodes, ends_d,
-                                                         target_order=b.end_order)
+                                                         target_order=b.end_order, cone=self.cone)
                 else:
-                    h_gnn = _sweep.sweep_forward_all(self.pmodel.gnn, g, b.level_nodes, ends_d, target_order=b.end_order)
+                    h_gnn = _sweep.sweep_forward_all(self.pmodel.gnn, g, b.level_nodes, ends_d, target_order=b.end_order,
+                                                     cone=self.cone)
             feat = self.cnn(b.images).reshape(b.B, -1) if self.cnn is not None else None
             pm = MaskedPathMap(b.masks, paths_d, feat, foff_d if b.B > 1 else None, *b.links) \
                 if feat is not None else None

@@ -342,3 +342,48 @@ def test_full_size_config_b_step_is_deterministic(dev):
     assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
     assert abs(runs[2][0] - runs[0][0]) < 1e-4 * abs(runs[0][0]) and rel_err(runs[2][1], runs[0][1]) < 1e-4
     assert bool(torch.isfinite(runs[0][2]).all())
+
+
+def test_cone_pruning_inside_the_training_step(dev):
+    """SURVEY 8f-1 inside the step: TrainStep(cone=True) builds the fan-in cone of the sampled endpoints as a per-node mask
+    on the device and the level kernels skip everything outside it.  Few endpoints of a 20 000-node design: predictions,
+    loss and every gradient equal the unpruned step (and the fp64 oracle); replayed from ONE captured HIP graph while the
+    endpoints - and the cone - change every step, the parameters follow the unpruned eager trajectory."""
+    from mmft.fusion import mse_loss
+    from mmft.synth import synth_design
+    from mmft.train import build_models, TrainStep, GraphedTrainStep
+    d = synth_design(N=20000, L=24, tile=32, seed=77, end_frac=0.2)
+    rng = np.random.default_rng(8)
+    batches = [[rng.permutation(d.num_paths)[:6].tolist()] for _ in range(6)]
+    res = {}
+    for cone in (False, True):
+        pmodel, cnn = build_models(map_size=d.map_size, device=dev, seed=5)
+        ts = TrainStep(pmodel, cnn, [d], dev, cone=cone)
+        hats, ends_d, ends_h = ts.forward(batches[0])
+        loss = mse_loss(hats, ts.batch.arrival[ends_d.long()].squeeze(-1))
+        ts.optim.zero_grad()
+        loss.backward()
+        grads = {k: p.grad.clone() for k, p in list(pmodel.named_parameters()) + list(cnn.named_parameters()) if p.grad is not None}
+        if cone:
+            frac = float(ts.batch.graph._cone_mask.float().mean())
+            assert 0 < frac < 0.6, frac                             # the cone really is a fraction of the design
+            stepper = GraphedTrainStep(ts, batches[0], warmup=0)
+        else:
+            stepper = ts
+            ts.forward(batches[0])                                  # the capture's dry run also advances BN running stats
+        for ids in batches:
+            out = stepper.step(ids)
+        torch.cuda.synchronize()
+        res[cone] = (hats.detach().clone(), float(loss), grads, float(out[0]), ts.optim.flat_param.clone(), ends_h.tolist())
+    assert res[True][5] == res[False][5]
+    assert rel_err(res[True][0], res[False][0]) < 1e-6 and abs(res[True][1] - res[False][1]) < 1e-6 * abs(res[False][1])
+    for k, gfull in res[False][2].items():
+        assert rel_err(res[True][2][k], gfull) < 1e-5, k
+    assert abs(res[True][3] - res[False][3]) < 2e-4 * abs(res[False][3])           # loss of the 6th step
+    assert rel_err(res[True][4], res[False][4]) < 2e-4                              # parameters after 6 steps
+    # and the oracle, fp64, on the first batch
+    pmodel, cnn = build_models(map_size=d.map_size, device='cpu', seed=5)
+    orc = R.OracleTrainer({k: v.clone() for k, v in pmodel.state_dict().items()},
+                          {k: v.clone() for k, v in cnn.state_dict().items()}, dtype=torch.float64)
+    h_o, tl, _ = orc.forward(d, R.design_csr(d), batches[0][0])
+    assert tl == res[True][5] and rel_err(res[True][0], h_o) < 1e-4
