@@ -608,7 +608,7 @@ def test_classification_task(dev):
         z, e_d, _ = ev.forward([np.arange(d.num_paths)])
         y = ev.batch.graph.ndata['label'][e_d.long()].squeeze(-1)
     pred = torch.argmax(torch.softmax(z, 1), dim=1)                                     # src/train.py:516
-    assert m['n'] == d.num_paths and abs(m['acc'] - float((pred == y).float().mean())) < 1e-9
+    assert m['n'] == d.num_paths and abs(m['acc'] - float((pred == y).double().mean())) < 1e-9
     assert (m['tp'], m['fn']) == (int(((pred != 0) & (y != 0)).sum()), int(((pred == 0) & (y != 0)).sum()))
     assert abs(m['loss'] - float(torch.nn.functional.cross_entropy(z.double(), y))) < 1e-5
 
