@@ -108,6 +108,16 @@ int mmft_mlp2_rows(const float* x1, long long ldx1, const int* rows, int n, cons
  * transitive fan-in cone of the step's sampled endpoints (mmft_fanin_cone_step).  Rows outside it are skipped - a tile of
  * 32 such rows exits at once - and their outputs are left untouched; the reverse pull does not read cell consumers outside
  * the cone.  The caller zero-fills G / DA for such a step (rows outside the cone must read as zero gradients). */
+/* MMFT_MATH_BF16 form of mmft_mlp2_rows with the weights PRE-PACKED as bf16 in [out][in] order (mmft_pack_bf16, once
+ * per sweep): w1_bf16 [HD][K1], w2_bf16 [D2][HD].  A lane's MFMA weight fragment is then one 16-byte global load and the
+ * weights never pass through LDS or a per-tile barrier - on the bf16 matrix pipe the arithmetic of a 32-row tile is 0.25 us
+ * and the fp32 kernel's weight-panel staging is what remains.  The reverse form (weights_kmajor = 1 of mmft_mlp2_rows) is
+ * this entry point fed with the transposed packs: w1_bf16 = bf16(W2g^T) [HD][D2], w2_bf16 = bf16(W1g^T) [K1][HD]. */
+int mmft_pack_bf16(const float* src, long long ld, int R, int C, void* dst_bf16, int transpose, int device, void* stream);
+int mmft_mlp2_rows_bf16(const float* x1, long long ldx1, const int* rows, int n, const void* w1_bf16, const float* b1,
+                        const void* w2_bf16, const float* b2, const float* mask, long long ldmask, float* hid_out,
+                        long long ldhid, float* out, long long ldout, int add_act, int relu_out, int K1, int HD, int D2,
+                        const unsigned char* active, int device, void* stream);
 /* out[c] (+)= sum_r g[idx[r]][c]   (bias gradients); workspace >= mmft_colsum_workspace_bytes */
 long long mmft_colsum_workspace_bytes(int rows, int cols);
 int mmft_colsum(const float* g, const int* idx, long long ld, int rows, int cols, float* out, int accumulate,

@@ -1,0 +1,197 @@
+// Lean bf16 form of the fused Linear-ReLU-Linear level kernel (MMFT_MATH_BF16), 128 -> 256 -> 128:
+//
+//   hid = mask ? (x1[rows] . W1^T) * (mask[rows] > 0) : relu(x1[rows] . W1^T + b1)
+//   out[rows] = add_act ? act(out[rows] + hid . W2^T + b2) : hid . W2^T + b2
+//
+// The fp32 kernel (mlp2.hip) is bound by its 2 x 128 KB fp32 weight panels: every workgroup pulls them from L2, parks
+// them in registers and stages them through LDS tile by tile (one or two barriers per 32-deep K tile), and its MFMA phase
+// alone is ~7 us.  On the bf16 pipe the arithmetic is 0.25 us, so this kernel is organised around what is left:
+//   * the weights arrive PRE-PACKED as bf16 in [n][k] order (mmft_pack_bf16, once per sweep: 4 x 64 KB), so a lane's
+//     MFMA A fragment - 8 consecutive k of one output feature - is ONE 16-byte global load; all 16 fragment loads of a
+//     wave (both layers) are issued at kernel entry and never touch LDS;
+//   * only the row operands go through LDS as bf16: the gathered x tile [32][128] and the hidden tile [32][256]
+//     (conflict-light ds_read_b128, 26 KB in all), two barriers in the whole kernel;
+//   * 8 waves per 32-row tile: wave w owns hidden columns [32w, 32w + 32) and output columns [16w, 16w + 16).
+// The reverse form (weights_kmajor in the fp32 kernel) is the same kernel fed with the transposed packs.
+#include "gemm_bf16.h"
+
+namespace mmft {
+
+constexpr int L2_BM = 32, L2_K1 = 128, L2_HD = 256, L2_D2 = 128;
+constexpr int L2_XS = L2_K1 + 8, L2_HS = L2_HD + 8;        // LDS row strides in bf16 elements (multiples of 8)
+
+struct Mlp2Bf16Args {
+  const float* x1;
+  long long ldx1;
+  const int* rows;
+  int n;
+  const unsigned short* w1;   // bf16 [HD][K1]
+  const float* b1;
+  const unsigned short* w2;   // bf16 [D2][HD]
+  const float* b2;
+  const float* mask;
+  long long ldmask;
+  float* hid_out;
+  long long ldhid;
+  float* out;
+  long long ldout;
+  int add_act, relu_out;
+  const unsigned char* active;
+};
+
+__global__ void __launch_bounds__(512) mlp2_rows_bf16_kernel(Mlp2Bf16Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned short xs[L2_BM * L2_XS];
+  __shared__ __attribute__((aligned(16))) unsigned short hs[L2_BM * L2_HS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * L2_BM;
+  auto live_row = [&](int r) -> bool { return m0 + r < a.n && (!a.active || a.active[a.rows[m0 + r]]); };
+  if (a.active) {
+    int any = 0;
+    if (tid < L2_BM) any = live_row(tid) ? 1 : 0;
+    if (!__syncthreads_or(any)) return;
+  }
+  const int r16 = lane & 15, q = lane >> 4;
+
+  // ---- every global load of the kernel: the wave's weight fragments of both layers, then the gathered x rows
+  bf16x8 w1f[2][4], w2f[8];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      w1f[j][ks] = *reinterpret_cast<const bf16x8*>(a.w1 + (long long)(wave * 32 + j * 16 + r16) * L2_K1 + ks * 32 + q * 8);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+    w2f[ks] = *reinterpret_cast<const bf16x8*>(a.w2 + (long long)(wave * 16 + r16) * L2_HD + ks * 32 + q * 8);
+  {
+    // 32 rows x 128 floats = 1024 groups of 4 floats, 2 per thread: thread -> (row, 8 consecutive k)
+    const int r = tid >> 4, k8 = (tid & 15) * 8;
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    if (live_row(r)) {
+      const float* p = a.x1 + (long long)a.rows[m0 + r] * a.ldx1 + k8;
+      v0 = *reinterpret_cast<const f32x4*>(p);
+      v1 = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    u32x4 pk = {pack_bf16(v0.x, v0.y), pack_bf16(v0.z, v0.w), pack_bf16(v1.x, v1.y), pack_bf16(v1.z, v1.w)};
+    *reinterpret_cast<u32x4*>(xs + r * L2_XS + k8) = pk;
+  }
+  __syncthreads();
+
+  // ---- phase 1: hidden columns [32 wave, 32 wave + 32) of the 32 rows
+  f32x4 acc1[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    bf16x8 xf[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(xs + (i * 16 + r16) * L2_XS + ks * 32 + q * 8);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[j][ks], xf[i], acc1[i][j], 0, 0, 0);
+  }
+  // lane holds hidden columns nn .. nn + 3 of row m: bias + ReLU, or the ReLU mask of the saved forward activations
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = i * 16 + r16, nn = wave * 32 + j * 16 + q * 4;
+      f32x4 v = acc1[i][j];
+      const bool live = live_row(m);
+      const long long row = live ? (long long)a.rows[m0 + m] : 0;
+      if (a.mask) {
+        f32x4 mk = {0.f, 0.f, 0.f, 0.f};
+        if (live) mk = *reinterpret_cast<const f32x4*>(a.mask + row * a.ldmask + nn);
+        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+        v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+      } else {
+        if (a.b1) v += *reinterpret_cast<const f32x4*>(a.b1 + nn);
+        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+        v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+      }
+      unsigned lo = pack_bf16(v.x, v.y), hi = pack_bf16(v.z, v.w);
+      *reinterpret_cast<unsigned long long*>(hs + m * L2_HS + nn) = ((unsigned long long)hi << 32) | lo;
+      if (a.hid_out && live) *reinterpret_cast<f32x4*>(a.hid_out + row * a.ldhid + nn) = v;
+    }
+  __syncthreads();
+
+  // ---- phase 2: output columns [16 wave, 16 wave + 16)
+  f32x4 acc2[2];
+  acc2[0] = acc2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      bf16x8 hf = *reinterpret_cast<const bf16x8*>(hs + (i * 16 + r16) * L2_HS + ks * 32 + q * 8);
+      acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[ks], hf, acc2[i], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = i * 16 + r16;
+    if (!live_row(m)) continue;
+    const int nn = wave * 16 + q * 4;
+    float* o = a.out + (long long)a.rows[m0 + m] * a.ldout + nn;
+    f32x4 v = acc2[i];
+    if (a.b2) v += *reinterpret_cast<const f32x4*>(a.b2 + nn);
+    if (a.add_act) v += *reinterpret_cast<const f32x4*>(o);
+    if (a.relu_out) {
+      v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+      v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(o) = v;
+  }
+}
+
+// dst[r][c] (bf16) = src[r][c], or with transpose dst[c][r] = src[r][c]   (R x C fp32, row stride ld)
+__global__ void __launch_bounds__(256) pack_bf16_kernel(const float* __restrict__ src, long long ld, int R, int C,
+                                                        unsigned short* __restrict__ dst, int transpose) {
+  const long long total = (long long)R * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    // i indexes the DESTINATION (coalesced stores); weights are tiny, the strided reads of the transposed form hit L2
+    int dr = (int)(i / (transpose ? R : C)), dc = (int)(i - (long long)dr * (transpose ? R : C));
+    float v = transpose ? src[(long long)dc * ld + dr] : src[(long long)dr * ld + dc];
+    dst[i] = (unsigned short)(pack_bf16(v, 0.f) & 0xffff);
+  }
+}
+
+}  // namespace mmft
+
+using namespace mmft;
+
+extern "C" int mmft_pack_bf16(const float* src, long long ld, int R, int C, void* dst, int transpose, int device,
+                              void* stream) {
+  MMFT_REQUIRE(src && dst && R > 0 && C > 0 && ld >= C, "pack_bf16: bad args");
+  DeviceGuard dg(device);
+  hipLaunchKernelGGL(pack_bf16_kernel, dim3(ew_grid((long long)R * C)), dim3(256), 0, (hipStream_t)stream, src, ld, R, C,
+                     (unsigned short*)dst, transpose);
+  return check_launch("pack_bf16");
+}
+
+extern "C" int mmft_mlp2_rows_bf16(const float* x1, long long ldx1, const int* rows, int n, const void* w1_bf16,
+                                   const float* b1, const void* w2_bf16, const float* b2, const float* mask,
+                                   long long ldmask, float* hid_out, long long ldhid, float* out, long long ldout,
+                                   int add_act, int relu_out, int K1, int HD, int D2, const unsigned char* active, int device,
+                                   void* stream) {
+  MMFT_REQUIRE(x1 && rows && w1_bf16 && w2_bf16 && out, "mlp2_rows_bf16: null pointer");
+  if (K1 != L2_K1 || HD != L2_HD || D2 != L2_D2) {
+    set_error("mlp2_rows_bf16: only %d -> %d -> %d is fused (got %d -> %d -> %d)", L2_K1, L2_HD, L2_D2, K1, HD, D2);
+    return MMFT_ERR_UNSUPPORTED;
+  }
+  MMFT_REQUIRE(n >= 0, "mlp2_rows_bf16: negative row count");
+  MMFT_REQUIRE(ldx1 % 4 == 0 && ldout % 4 == 0 && aligned16(x1) && aligned16(out) && aligned16(w1_bf16) && aligned16(w2_bf16) &&
+                   (!b1 || aligned16(b1)) && (!b2 || aligned16(b2)),
+               "mlp2_rows_bf16: operands must be 16-byte aligned");
+  MMFT_REQUIRE(!mask || (ldmask % 4 == 0 && aligned16(mask)), "mlp2_rows_bf16: mask alignment");
+  MMFT_REQUIRE(!hid_out || (ldhid % 4 == 0 && aligned16(hid_out)), "mlp2_rows_bf16: hid_out alignment");
+  if (n == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  Mlp2Bf16Args a{x1, ldx1, rows, n, (const unsigned short*)w1_bf16, b1, (const unsigned short*)w2_bf16, b2, mask, ldmask,
+                 hid_out, ldhid, out, ldout, add_act, relu_out, active};
+  const double fl = 2.0 * n * ((double)K1 * HD + (double)HD * D2), by = 4.0 * n * ((double)K1 + 2.0 * HD + 2.0 * D2);
+  MMFT_LAUNCH(mask ? "mlp2_rows_bf16_kernel<bwd>" : "mlp2_rows_bf16_kernel<fwd>", fl, by, mlp2_rows_bf16_kernel,
+              dim3(cdiv(n, L2_BM)), dim3(512), (hipStream_t)stream, a);
+  return check_launch("mlp2_rows_bf16");
+}

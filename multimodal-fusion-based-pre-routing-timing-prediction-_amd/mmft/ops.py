@@ -198,6 +198,36 @@ def mlp2_rows(x1, rows, w1, b1, w2, b2, out, kmajor=False, mask=None, hid_out=No
     return out
 
 
+def pack_bf16(w, transpose=False):
+    """bf16 copy of a small fp32 matrix ([R, C] -> [R, C], or [C, R] with transpose) for the pre-packed bf16 kernels."""
+    _rows2d(w, 'w')
+    R, C = w.shape
+    out = torch.empty((C, R) if transpose else (R, C), dtype=torch.bfloat16, device=w.device)
+    dev, st = lib.stream_args(w)
+    lib.call('mmft_pack_bf16', w, w.stride(0), R, C, out, int(transpose), dev, st)
+    return out
+
+
+def mlp2_rows_bf16(x1, rows, w1p, b1, w2p, b2, out, mask=None, hid_out=None, add_act=False, relu_out=False, active=None):
+    """Fused Linear-ReLU-Linear over gathered rows with pre-packed bf16 weights (mmft_mlp2_rows_bf16)."""
+    _rows2d(x1, 'x1'); _rows2d(out, 'out'); _idx(rows, 'rows')
+    for t, nm, shape in ((w1p, 'w1p', (256, 128)), (w2p, 'w2p', (128, 256))):
+        if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.bfloat16 and tuple(t.shape) == shape and t.is_contiguous()):
+            raise ValueError(f'mlp2_rows_bf16: {nm} must be a contiguous bf16 CUDA tensor of shape {shape}')
+    if x1.shape[1] != 128 or out.shape[1] != 128 or out.shape[0] != x1.shape[0]:
+        raise ValueError('mlp2_rows_bf16: 128 -> 256 -> 128 over node-indexed buffers')
+    for t, nm in ((mask, 'mask'), (hid_out, 'hid_out')):
+        if t is not None:
+            _rows2d(t, nm)
+            if t.shape[1] != 256 or t.shape[0] != x1.shape[0]:
+                raise ValueError(f'mlp2_rows_bf16: {nm} must be [rows of x1, 256]')
+    dev, st = lib.stream_args(x1)
+    lib.call('mmft_mlp2_rows_bf16', x1, x1.stride(0), rows, rows.numel(), w1p, b1, w2p, b2, mask,
+             mask.stride(0) if mask is not None else 0, hid_out, hid_out.stride(0) if hid_out is not None else 0, out,
+             out.stride(0), int(add_act), int(relu_out), 128, 256, 128, _active(active, x1.shape[0]), dev, st)
+    return out
+
+
 def _active(active, N):
     if active is None:
         return None

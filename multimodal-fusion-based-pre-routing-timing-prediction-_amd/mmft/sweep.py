@@ -16,7 +16,7 @@ two small GEMMs that turn G into DA.  Weight gradients are NOT computed per leve
 (last to run) computes all of them in batched GEMMs over every node of the sweep.
 """
 import torch
-from . import ops, gradsink
+from . import ops, gradsink, lib
 
 _MLP_KEYS = ('fc_cell_self', 'fc_net_self', 'fc_cell_neigh')
 
@@ -59,6 +59,7 @@ class SweepState:
         self.fold = None                    # static facts for the folded level kernels (PinGraph.fold_schedule)
         self.PRE = None
         self.attn = None                    # attention branch (flag_attn): dict(key, c12, alpha, dcp, o2i)
+        self.wpack = None                   # bf16 math mode: fc_cell_neigh pre-packed as bf16 (W1, W2, W2^T, W1^T)
         self.active = None                  # uint8 per node: fan-in cone of the step's endpoints (None: every node)
         self.spec_lists = None              # speculative drop-in sweep: the level lists it ran with, its token, target rows
         self.spec_token = None
@@ -176,7 +177,10 @@ def _w(p):
 
 def _cell_neigh_fwd(st, rows, w1g, b1g, w2g, b2g, act):
     """h[rows] = act(h[rows] + fc_cell_neigh(A[rows])), HN[rows] saved: one fused launch when the widths allow."""
-    if ops.mlp2_fusable(st.D, st.Hd, st.D):
+    if st.wpack is not None:
+        ops.mlp2_rows_bf16(st.A, rows, st.wpack[0], b1g, st.wpack[1], b2g, st.h, hid_out=st.HN, add_act=True,
+                           relu_out=(act == ops.ACT_RELU), active=st.active)
+    elif ops.mlp2_fusable(st.D, st.Hd, st.D):
         ops.mlp2_rows(st.A, rows, w1g, b1g, w2g, b2g, st.h, kmajor=False, hid_out=st.HN, add_act=True,
                       relu_out=(act == ops.ACT_RELU), active=st.active)
     else:
@@ -193,6 +197,10 @@ def _cell_neigh_bwd(st, rows, w1g, w2g, keep_dhn=False):
             if st.DHN is None:
                 st.DHN = st._buf('DHN', st.Hd)
             dhn_out = st.DHN
+        if st.wpack is not None:
+            ops.mlp2_rows_bf16(st.G, rows, st.wpack[2], None, st.wpack[3], None, st.DA, mask=st.HN, hid_out=dhn_out,
+                               active=st.active)
+            return
         ops.mlp2_rows(st.G, rows, w2g, None, w1g, None, st.DA, kmajor=True, mask=st.HN, hid_out=dhn_out, active=st.active)
     else:
         dhn = ops.linear_dgrad(st.G, w2g, gidx=rows, mask=st.HN, maskidx=rows)
@@ -471,6 +479,11 @@ class SweepFn(torch.autograd.Function):
         (w1c, b1c, w2c, b2c, w1n, b1n, w2n, b2n, w1g, b1g, w2g, b2g) = P
         act = ops.ACT_RELU if st.relu else ops.ACT_NONE
         st.levels = [(l, r) for l, r in enumerate(level_rows)]
+        st.wpack = None
+        if lib.get_math_mode() == 'bf16' and ops.mlp2_fusable(st.D, st.Hd, st.D):
+            # the level chain's fused MLP takes its weights pre-packed as bf16 (forward: W1, W2; reverse: W2^T, W1^T)
+            st.wpack = (ops.pack_bf16(w1g), ops.pack_bf16(w2g), ops.pack_bf16(w2g, transpose=True),
+                        ops.pack_bf16(w1g, transpose=True))
         r0 = level_rows[0]
         rc2 = _cat_rows(st, lambda l: l % 2 == 0 and l > 0)
         rn = _cat_rows(st, lambda l: l % 2 == 1)

@@ -120,6 +120,47 @@ def test_mlp2_rows_fused(dev, n):
     assert rel_err(da[r.to(dev)], dref) < TOL
 
 
+@pytest.mark.parametrize('n', [1, 33, 1000, 8064])
+@pytest.mark.parametrize('representable', [True, False])
+def test_mlp2_rows_prepacked(dev, n, representable):
+    """The lean level kernel with pre-packed bf16 weights (mmft_pack_bf16 + mmft_mlp2_rows_bf16), forward and reverse
+    form (transposed packs).  With bf16-representable x and weights the FIRST layer is exact (2e-6); the hidden tile is
+    rounded to bf16 between the layers, so the second layer carries the stated bf16 tolerance."""
+    N = n + 50
+    x1, w1, b1 = rnd(N, 128, seed=10, representable=representable), bf(rnd(256, 128, seed=11) * 0.1), rnd(256, seed=12) * 0.1
+    w2, b2 = bf(rnd(128, 256, seed=13) * 0.1), rnd(128, seed=14) * 0.1
+    rows = torch.randperm(N)[:n].to(torch.int32)
+    old = rnd(N, 128, seed=15)
+    out, hid = old.clone().to(dev), torch.zeros(N, 256, device=dev)
+    w1d, w2d = w1.to(dev), w2.to(dev)
+    p1, p2 = ops.pack_bf16(w1d), ops.pack_bf16(w2d)
+    assert torch.equal(p1.float().cpu(), w1) and torch.equal(ops.pack_bf16(w2d, transpose=True).float().cpu(), w2.T.contiguous())
+    ops.mlp2_rows_bf16(x1.to(dev), rows.to(dev), p1, b1.to(dev), p2, b2.to(dev), out, hid_out=hid, add_act=True, relu_out=True)
+    r = rows.long()
+    h = torch.relu(x1[r].double() @ w1.double().T + b1.double())
+    assert rel_err(hid[r.to(dev)], h) < (EXACT if representable else TOL)
+    hk = hid[r.to(dev)].cpu().double()                        # second layer from the kernel's own hidden tile
+    ref = old.double().clone()
+    ref[r] = torch.relu(old[r].double() + bf(hk.float()).double() @ w2.double().T + b2.double())
+    assert rel_err(out, ref) < 1e-5                                      # exact given the bf16-rounded hidden tile
+    untouched = torch.ones(N, dtype=torch.bool); untouched[r] = False
+    assert torch.equal(out.cpu()[untouched], old[untouched])
+    # reverse form
+    g = rnd(N, 128, seed=16, representable=representable)
+    da = torch.zeros(N, 128, device=dev)
+    dh = torch.zeros(N, 256, device=dev)
+    ops.mlp2_rows_bf16(g.to(dev), rows.to(dev), ops.pack_bf16(w2d, transpose=True), None, ops.pack_bf16(w1d, transpose=True), None,
+                       da, mask=hid, hid_out=dh)
+    dhr = (g[r].double() @ w2.double()) * (hid[r.to(dev)].cpu() > 0)
+    assert rel_err(dh[r.to(dev)], dhr) < (EXACT if representable else TOL)
+    assert rel_err(da[r.to(dev)], bf(dh[r.to(dev)].cpu()).double() @ w1.double()) < 1e-5
+    # cone mask: rows outside it are left alone
+    active = torch.zeros(N, dtype=torch.uint8); active[r[::2]] = 1
+    out2 = old.clone().to(dev)
+    ops.mlp2_rows_bf16(x1.to(dev), rows.to(dev), p1, b1.to(dev), p2, b2.to(dev), out2, add_act=True, relu_out=True, active=active.to(dev))
+    assert torch.equal(out2.cpu()[r[::2]], out.cpu()[r[::2]]) and torch.equal(out2.cpu()[r[1::2]], old[r[1::2]])
+
+
 @pytest.mark.parametrize('fin,n', [(36, 5000), (2, 4099), (48, 37)])
 def test_first_layer_grads_fused(dev, fin, n):
     g, hid, x, w2 = rnd(n, 128, seed=17), rnd(n, 256, seed=18), rnd(n, fin, seed=19), rnd(128, 256, seed=20) * 0.1
