@@ -181,7 +181,10 @@ def main():
                     help="cell fan-in distribution of the synthetic netlist ('irregular' = config E's Zipf skew)")
     ap.add_argument('--mode', default='sweep', choices=['sweep', 'dropin'])
     ap.add_argument('--no-overlap', action='store_true', help='run the sweep and the CNN on one stream')
-    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying one HIP graph')
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying HIP graphs')
+    ap.add_argument('--single-graph', action='store_true',
+                    help='capture the step as ONE graph with an in-graph two-stream fork (round-1 form) instead of five '
+                         'single-stream graphs replayed on two streams')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
@@ -235,9 +238,9 @@ def main():
     if args.mode == 'sweep' and not args.no_graph:
         from mmft.train import GraphedTrainStep
         try:
-            stepper = GraphedTrainStep(ts, sample_paths(designs, args.batch_paths, rng))
+            stepper = GraphedTrainStep(ts, sample_paths(designs, args.batch_paths, rng), pieces=not args.single_graph)
             graphed = True
-            log('train step captured as one HIP graph')
+            log('train step captured (%s)' % ('five single-stream HIP graphs on two streams' if stepper.pieces else 'one HIP graph'))
         except Exception as e:                       # noqa: BLE001 - report and keep the eager path
             log(f'HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly')
             stepper = ts
@@ -332,7 +335,7 @@ def main():
         pm2.load_state_dict(pm_state)
         cnn2.load_state_dict(pc_state)
         ts2 = TrainStep(pm2, cnn2, designs, dev, world_size=1, mode=args.mode, overlap=not args.no_overlap)
-        gs2 = GraphedTrainStep(ts2, HISTORY[0])
+        gs2 = GraphedTrainStep(ts2, HISTORY[0], pieces=not args.single_graph)
         for ids in HISTORY[1:]:
             gs2.step(ids)
         torch.cuda.synchronize()
@@ -370,7 +373,8 @@ def main():
                 'designs_per_step_per_gpu': args.designs, 'nodes': args.nodes, 'levels': args.levels,
                 'tile': args.tile, 'endpoints_per_design': args.batch_paths, 'cone_pruning': bool(args.cone),
                 'parallelism': f'dp{world} (designs sharded, one all-reduce of the flat gradient per step)',
-                'launch': ('one HIP graph replay per step' + ('' if world == 1 else ' (forward+backward) + eager all-reduce + Adam'))
+                'launch': (('five single-stream HIP graphs replayed on two streams per step' if stepper.pieces else 'one HIP graph replay per step')
+                           + (' + eager Adam' if world == 1 else ' + eager bucketed all-reduce + Adam'))
                 if graphed else 'eager launches',
                 'api': 'PathModel.forward_sweep (whole-sweep entry; per-level drop-in path: --mode dropin)' if args.mode == 'sweep' else 'drop-in per-level model() calls',
             },

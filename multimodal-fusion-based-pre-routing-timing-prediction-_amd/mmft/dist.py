@@ -117,3 +117,20 @@ class GradReducer:
             self._reduce(i, None, streams=[main])
         main.wait_stream(self.comm)
         self.optim.step_count += 1
+
+    def reduce_bucket(self, i, events):
+        """Piecewise-graph step: bucket i is complete once `events` have fired - all-reduce + Adam on the communication
+        stream while the remaining pieces of the backward pass run."""
+        self._pending = getattr(self, '_pending', set(range(len(self.buckets))))
+        self._reduce(i, events)
+        self._pending.discard(i)
+
+    def reduce_rest_and_join(self, main):
+        """After the last backward piece was enqueued on `main` (and `main` has waited for the side stream): reduce the
+        buckets not handed over yet, make `main` wait for the communication stream."""
+        pending = sorted(getattr(self, '_pending', set(range(len(self.buckets)))))
+        for i in pending:
+            self._reduce(i, None, streams=[main])
+        self._pending = set(range(len(self.buckets)))
+        main.wait_stream(self.comm)
+        self.optim.step_count += 1

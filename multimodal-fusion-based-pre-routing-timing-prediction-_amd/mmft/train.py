@@ -219,16 +219,23 @@ class TrainStep:
             from . import sweep as _sweep
             cur = torch.cuda.current_stream(self.device)
             h_gnn = None
+            import os as _os
+            cnn_first = _os.environ.get('MMFT_ISSUE_ORDER') == 'cnn_first' and self.overlap and self.cnn is not None
+            if cnn_first:
+                self.side.wait_stream(cur)
+                feat = self.cnn(b.images).reshape(b.B, -1)
             if self.pmodel.gnn is not None:
                 if self.overlap:
-                    self.side.wait_stream(cur)
+                    if not cnn_first:
+                        self.side.wait_stream(cur)
                     with torch.cuda.stream(self.side):
                         h_gnn = _sweep.sweep_forward_all(self.pmodel.gnn, g, b.level_nodes, ends_d,
                                                          target_order=b.end_order, cone=self.cone)
                 else:
                     h_gnn = _sweep.sweep_forward_all(self.pmodel.gnn, g, b.level_nodes, ends_d, target_order=b.end_order,
                                                      cone=self.cone)
-            feat = self.cnn(b.images).reshape(b.B, -1) if self.cnn is not None else None
+            if not cnn_first:
+                feat = self.cnn(b.images).reshape(b.B, -1) if self.cnn is not None else None
             pm = MaskedPathMap(b.masks, paths_d, feat, foff_d if b.B > 1 else None, *b.links) \
                 if feat is not None else None
             # the masked projection needs only the CNN output: issue it before joining the sweep stream
@@ -286,18 +293,36 @@ class TrainStep:
 
 
 class GraphedTrainStep:
-    """The whole mini-batch (forward, MSE, backward, fused Adam) captured ONCE as a HIP graph and replayed per
-    step: the ~550 kernel launches of a step then cost no host time.  Per step the host only packs the sampled
-    endpoints into a pinned int32 staging slot (one asynchronous H2D copy into a static device buffer); Adam's step
-    counter lives on the device, so nothing else is uploaded.  Requires a constant number of sampled paths per step.  Under data parallelism the
-    graph holds forward + backward only; each gradient bucket's RCCL all-reduce + Adam launch are issued eagerly
-    behind the replay on the communication stream (mmft.dist.GradReducer), so no collective is ever captured."""
+    """The whole mini-batch (forward, loss, backward, fused Adam) captured ONCE and replayed per step: the ~450 kernel
+    launches of a step then cost no host time.  Per step the host only packs the sampled endpoints into a pinned int32
+    staging slot (one asynchronous H2D copy into a static device buffer); Adam's step counter lives on the device, so
+    nothing else is uploaded.  Requires a constant number of sampled paths per step.
 
-    def __init__(self, ts, example_path_ids, warmup=3):
+    pieces=True (default): the step is captured as FIVE single-stream HIP graphs that are replayed on two streams with
+    ordinary events between them,
+
+        side stream :  [A  netlist sweep forward]                  [bA  reverse sweep + GNN weight gradients]
+        main stream :  [B  U-Net forward + masked projection] [H  fusion head, loss, head backward] [bB  U-Net backward] Adam
+
+    because the two-stream fork INSIDE one captured graph does not run its branches side by side on this stack
+    (rocprofv3 kernel trace, tools/trace_overlap.py: the second branch of a fork starts 0.8 - 2.2 ms after its
+    dependencies are met, once most of the first branch has been issued, so the latency-bound level chain and the chip-
+    filling U-Net kernels ran one after the other: 6.4 of 7.2 ms with ONE kernel in flight).  Separate graphs on separate
+    streams overlap like eager launches do.  The autograd graph is cut at the two tensors that cross the boundary (the
+    endpoint embeddings and the CNN feature map: detached leaves on the head's side, their .grad fed to the backward
+    piece of the producer), so every piece has a backward of its own.  The cuts are also where a data-parallel step
+    hands a finished gradient bucket to the communication stream: the head's bucket is all-reduced underneath bA / bB.
+
+    pieces=False: one graph for the whole step (the round-1 form), kept for comparison.  No collective is ever captured.
+    """
+
+    def __init__(self, ts, example_path_ids, warmup=3, pieces=True):
         if not ts.fused or ts.mode != 'sweep':
             raise ValueError('GraphedTrainStep needs mode="sweep" and the fused optimizer')
         self.ts = ts
         b = ts.batch
+        self.pieces = bool(pieces) and ts.overlap and ts.pmodel.gnn is not None and ts.cnn is not None and \
+            ts.pmodel.fcn is not None
         for _ in range(warmup):                       # optional eager optimizer steps before the capture
             ts.step(example_path_ids)
         # one eager forward + backward WITHOUT an optimizer step: uploads the cached level rows and allocates
@@ -323,19 +348,55 @@ class GraphedTrainStep:
         self.T = T
         sel = b.select(example_path_ids, static=self.static_idx)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        # thread_local: RCCL's watchdog thread may query events while this thread captures
-        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-            hats, ends_d, _ = ts.forward(None, _sel=sel)
+        if self.pieces:
+            self._capture_pieces(sel)
+        else:
+            self.graph = torch.cuda.CUDAGraph()
+            # thread_local: RCCL's watchdog thread may query events while this thread captures
+            with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+                hats, ends_d, _ = ts.forward(None, _sel=sel)
+                loss = ts.loss(hats, ends_d)
+                ts.optim.zero_grad()
+                loss.backward()                      # data parallel: the buckets are reduced behind every replay
+                if ts.reducer is None:
+                    ts.optim.step_captured()
+                self.loss, self.hats = loss.detach(), hats.detach()
+        torch.cuda.synchronize()
+
+    def _capture_pieces(self, sel):
+        from . import sweep as _sweep
+        ts, b = self.ts, self.ts.batch
+        pm_, cnn, g = ts.pmodel, ts.cnn, ts.batch.graph
+        ends_d, paths_d, foff_d, counts, ends_h, lv_d = sel
+        skip = ('gnn.fc_net_drive.', 'gnn.fc_attn2.')
+        named = [(n, p) for n, p in pm_.named_parameters() if not n.startswith(skip)]
+        head_params = [p for n, p in named if not n.startswith(('gnn.', 'cnn.'))]
+        gnn_params = [p for n, p in named if n.startswith('gnn.')]
+        cnn_params = list(cnn.parameters())
+        pool = torch.cuda.graph_pool_handle()
+        mk = lambda: torch.cuda.CUDAGraph()
+        self.gA, self.gB, self.gH, self.gbA, self.gbB = mk(), mk(), mk(), mk(), mk()
+        kw = dict(pool=pool, capture_error_mode='thread_local')
+        g.ndata['h'] = ts.h
+        with torch.cuda.graph(self.gA, stream=ts.side, **kw):                       # A: netlist sweep forward
+            h_out = _sweep.sweep_forward_all(pm_.gnn, g, b.level_nodes, ends_d, target_order=b.end_order, cone=ts.cone)
+            h_leaf = h_out.detach().requires_grad_(True)
+        with torch.cuda.graph(self.gB, **kw):                                       # B: U-Net forward
+            feat_out = cnn(b.images).reshape(b.B, -1)
+            feat_leaf = feat_out.detach().requires_grad_(True)
+        with torch.cuda.graph(self.gH, **kw):                                       # H: head forward, loss, head backward
+            pmap = MaskedPathMap(b.masks, paths_d, feat_leaf, foff_d if b.B > 1 else None, *b.links)
+            hats = pm_.fuse_heads(h_leaf, pmap, lv_d, b.L, h_cnn=pm_._fcn(pmap))
             loss = ts.loss(hats, ends_d)
             ts.optim.zero_grad()
-            if ts.reducer is not None:
-                loss.backward()                      # the buckets are reduced behind every replay (GradReducer)
-            else:
-                loss.backward()
-                ts.optim.step_captured()
+            torch.autograd.backward(loss, inputs=head_params + [h_leaf, feat_leaf])
             self.loss, self.hats = loss.detach(), hats.detach()
-        torch.cuda.synchronize()
+        with torch.cuda.graph(self.gbA, stream=ts.side, **kw):                      # bA: reverse sweep + GNN weight grads
+            torch.autograd.backward(h_out, grad_tensors=h_leaf.grad, inputs=gnn_params)
+        with torch.cuda.graph(self.gbB, **kw):                                      # bB: U-Net backward
+            torch.autograd.backward(feat_out, grad_tensors=feat_leaf.grad, inputs=cnn_params)
+        self._keep = (h_out, h_leaf, feat_out, feat_leaf, pmap)
+        self._ev = [torch.cuda.Event() for _ in range(4)]
 
     def step(self, path_ids_per_design):
         """Host side of a step: pack the sampled endpoints (pinned staging slot -> one async H2D copy), replay.  No
@@ -343,9 +404,34 @@ class GraphedTrainStep:
         ts, b = self.ts, self.ts.batch
         sel = b.select(path_ids_per_design, static=self.static_idx)
         ts.last_ends = sel[0]
-        self.graph.replay()
+        if not self.pieces:
+            self.graph.replay()
+            if ts.reducer is not None:
+                ts.reducer.after_replay()        # per bucket: all-reduce + Adam on the communication stream
+            else:
+                ts.optim.note_replay()
+            return self.loss, self.hats, sel[4].tolist()
+        main, side = torch.cuda.current_stream(ts.device), ts.side
+        e0, eA, eH, ebA = self._ev
+        e0.record(main)                          # the endpoint indices are in place (and the previous step's Adam is done)
+        side.wait_event(e0)
+        with torch.cuda.stream(side):
+            self.gA.replay()
+            eA.record(side)
+        self.gB.replay()
+        main.wait_event(eA)
+        self.gH.replay()
+        eH.record(main)
+        side.wait_event(eH)
         if ts.reducer is not None:
-            ts.reducer.after_replay()        # per bucket: all-reduce + Adam on the communication stream
+            ts.reducer.reduce_bucket(0, [eH])    # the head's gradients are final: all-reduce them under bA / bB
+        with torch.cuda.stream(side):
+            self.gbA.replay()
+            ebA.record(side)
+        self.gbB.replay()
+        main.wait_event(ebA)
+        if ts.reducer is not None:
+            ts.reducer.reduce_rest_and_join(main)
         else:
-            ts.optim.note_replay()
+            ts.optim.step()
         return self.loss, self.hats, sel[4].tolist()
