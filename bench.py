@@ -182,9 +182,10 @@ def main():
     ap.add_argument('--mode', default='sweep', choices=['sweep', 'dropin'])
     ap.add_argument('--no-overlap', action='store_true', help='run the sweep and the CNN on one stream')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying HIP graphs')
-    ap.add_argument('--single-graph', action='store_true',
-                    help='capture the step as ONE graph with an in-graph two-stream fork (round-1 form) instead of five '
-                         'single-stream graphs replayed on two streams')
+    ap.add_argument('--graph-pieces', default='auto', choices=['auto', 'one', 'five'],
+                    help="'one': the step is ONE HIP graph (in-graph two-stream fork); 'five': five single-stream graphs "
+                         "replayed on two streams (gradient buckets handed to the communication stream at the cuts); "
+                         "'auto': one on a single GPU, five under data parallelism")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
@@ -238,7 +239,7 @@ def main():
     if args.mode == 'sweep' and not args.no_graph:
         from mmft.train import GraphedTrainStep
         try:
-            stepper = GraphedTrainStep(ts, sample_paths(designs, args.batch_paths, rng), pieces=not args.single_graph)
+            stepper = GraphedTrainStep(ts, sample_paths(designs, args.batch_paths, rng), pieces={'auto': None, 'one': False, 'five': True}[args.graph_pieces])
             graphed = True
             log('train step captured (%s)' % ('five single-stream HIP graphs on two streams' if stepper.pieces else 'one HIP graph'))
         except Exception as e:                       # noqa: BLE001 - report and keep the eager path
@@ -335,7 +336,7 @@ def main():
         pm2.load_state_dict(pm_state)
         cnn2.load_state_dict(pc_state)
         ts2 = TrainStep(pm2, cnn2, designs, dev, world_size=1, mode=args.mode, overlap=not args.no_overlap)
-        gs2 = GraphedTrainStep(ts2, HISTORY[0], pieces=not args.single_graph)
+        gs2 = GraphedTrainStep(ts2, HISTORY[0], pieces={'auto': None, 'one': False, 'five': True}[args.graph_pieces])
         for ids in HISTORY[1:]:
             gs2.step(ids)
         torch.cuda.synchronize()

@@ -178,7 +178,8 @@ class TrainStep:
         # (device-side mask per step; pays when few endpoints of a large design are sampled, see sweep_forward_all)
         self.cone = bool(cone) and mode == 'sweep'
         self.overlap = overlap and mode == 'sweep'
-        self.side = torch.cuda.Stream(device=device) if self.overlap else None
+        import os as _os
+        self.side = torch.cuda.Stream(device=device, priority=int(_os.environ.get('MMFT_SIDE_PRIORITY', '0'))) if self.overlap else None
         self.pmodel, self.cnn = pmodel, cnn
         self.device = torch.device(device)
         self.batch = DesignBatch(designs, device, pmodel.gnn.out_feat_dim if pmodel.gnn is not None else 128)
@@ -298,29 +299,32 @@ class GraphedTrainStep:
     staging slot (one asynchronous H2D copy into a static device buffer); Adam's step counter lives on the device, so
     nothing else is uploaded.  Requires a constant number of sampled paths per step.
 
-    pieces=True (default): the step is captured as FIVE single-stream HIP graphs that are replayed on two streams with
-    ordinary events between them,
+    pieces=False (default on one GPU): ONE graph for the whole step, the netlist sweep forked onto a side stream inside
+    it.  pieces=True (default under data parallelism): the step is captured as FIVE single-stream HIP graphs that are
+    replayed on two streams with ordinary events between them,
 
         side stream :  [A  netlist sweep forward]                  [bA  reverse sweep + GNN weight gradients]
-        main stream :  [B  U-Net forward + masked projection] [H  fusion head, loss, head backward] [bB  U-Net backward] Adam
+        main stream :  [B  U-Net forward] [H  fusion head, loss, head backward] [bB  U-Net backward] Adam
 
-    because the two-stream fork INSIDE one captured graph does not run its branches side by side on this stack
-    (rocprofv3 kernel trace, tools/trace_overlap.py: the second branch of a fork starts 0.8 - 2.2 ms after its
-    dependencies are met, once most of the first branch has been issued, so the latency-bound level chain and the chip-
-    filling U-Net kernels ran one after the other: 6.4 of 7.2 ms with ONE kernel in flight).  Separate graphs on separate
-    streams overlap like eager launches do.  The autograd graph is cut at the two tensors that cross the boundary (the
-    endpoint embeddings and the CNN feature map: detached leaves on the head's side, their .grad fed to the backward
-    piece of the producer), so every piece has a backward of its own.  The cuts are also where a data-parallel step
-    hands a finished gradient bucket to the communication stream: the head's bucket is all-reduced underneath bA / bB.
-
-    pieces=False: one graph for the whole step (the round-1 form), kept for comparison.  No collective is ever captured.
+    The autograd graph is cut at the two tensors that cross the boundaries (the endpoint embeddings and the CNN feature
+    map: detached leaves on the head's side, their .grad fed to the backward piece of the producer), so every piece has
+    a backward of its own.  The cut behind H is where a data-parallel step hands the head's finished gradient bucket
+    (2.27 M of 2.89 M parameters) to the communication stream: it is all-reduced underneath bA / bB - inside one
+    captured graph no point in the middle can be signalled to an outside stream on this stack (mmft.dist.GradReducer).
+    Measured on one GPU (rocprofv3 kernel traces, tools/trace_overlap.py, tools/replay_host_time.py) both forms give the
+    same step time within 0.2 ms: the sweep and the U-Net overlap only partially in either (A + B in isolation: 1.43 +
+    0.92 ms alone, 1.94 ms together) because the level chain's dependent launches wait for CU slots behind the U-Net's
+    chip-filling kernels - contention, not a scheduling artefact - so the single graph (one launch, Adam inside) stays
+    the one-GPU default.  No collective is ever captured.
     """
 
-    def __init__(self, ts, example_path_ids, warmup=3, pieces=True):
+    def __init__(self, ts, example_path_ids, warmup=3, pieces=None):
         if not ts.fused or ts.mode != 'sweep':
             raise ValueError('GraphedTrainStep needs mode="sweep" and the fused optimizer')
         self.ts = ts
         b = ts.batch
+        if pieces is None:
+            pieces = ts.world_size > 1          # see the class docstring: the cuts pay for themselves under data parallelism
         self.pieces = bool(pieces) and ts.overlap and ts.pmodel.gnn is not None and ts.cnn is not None and \
             ts.pmodel.fcn is not None
         for _ in range(warmup):                       # optional eager optimizer steps before the capture
