@@ -178,8 +178,7 @@ class TrainStep:
         # (device-side mask per step; pays when few endpoints of a large design are sampled, see sweep_forward_all)
         self.cone = bool(cone) and mode == 'sweep'
         self.overlap = overlap and mode == 'sweep'
-        import os as _os
-        self.side = torch.cuda.Stream(device=device, priority=int(_os.environ.get('MMFT_SIDE_PRIORITY', '0'))) if self.overlap else None
+        self.side = torch.cuda.Stream(device=device) if self.overlap else None
         self.pmodel, self.cnn = pmodel, cnn
         self.device = torch.device(device)
         self.batch = DesignBatch(designs, device, pmodel.gnn.out_feat_dim if pmodel.gnn is not None else 128)
@@ -220,23 +219,16 @@ class TrainStep:
             from . import sweep as _sweep
             cur = torch.cuda.current_stream(self.device)
             h_gnn = None
-            import os as _os
-            cnn_first = _os.environ.get('MMFT_ISSUE_ORDER') == 'cnn_first' and self.overlap and self.cnn is not None
-            if cnn_first:
-                self.side.wait_stream(cur)
-                feat = self.cnn(b.images).reshape(b.B, -1)
             if self.pmodel.gnn is not None:
                 if self.overlap:
-                    if not cnn_first:
-                        self.side.wait_stream(cur)
+                    self.side.wait_stream(cur)
                     with torch.cuda.stream(self.side):
                         h_gnn = _sweep.sweep_forward_all(self.pmodel.gnn, g, b.level_nodes, ends_d,
                                                          target_order=b.end_order, cone=self.cone)
                 else:
                     h_gnn = _sweep.sweep_forward_all(self.pmodel.gnn, g, b.level_nodes, ends_d, target_order=b.end_order,
                                                      cone=self.cone)
-            if not cnn_first:
-                feat = self.cnn(b.images).reshape(b.B, -1) if self.cnn is not None else None
+            feat = self.cnn(b.images).reshape(b.B, -1) if self.cnn is not None else None
             pm = MaskedPathMap(b.masks, paths_d, feat, foff_d if b.B > 1 else None, *b.links) \
                 if feat is not None else None
             # the masked projection needs only the CNN output: issue it before joining the sweep stream
