@@ -23,7 +23,9 @@ def test_bench_line_contract(dev):
                      ('config', dict), ('roofline', dict), ('cpu_baseline', dict)):
         assert isinstance(j[key], typ), key
     assert 'vs_baseline' in j and j['vs_baseline'] is None          # BASELINE.md holds no published number
-    assert j['n_gpus'] == 1 and j['steps'] == 3 and j['warmup'] == 1 and j['scaling'] == 'weak' and j['dtype'] == 'f32'
+    assert j['n_gpus'] == 1 and j['steps'] == 3 and j['warmup'] == 1 and j['scaling'] == 'weak' and j['dtype'] == 'bf16'
+    f32 = j['heldout_eval_f32_same_schedule']                        # the same schedule replayed in exact fp32
+    assert f32 is not None and f32['ms_per_step'] > 0 and abs(f32['mae_drift']) < 1.0
     assert j['higher_is_better'] is True and 'workload' in j['config'] and j['value'] > 0
     assert abs(j['value'] - 2 * 3 / (j['ms_per_step'] * 3 / 1e3)) / j['value'] < 1e-6      # designs / s over the timed steps
     r = j['roofline']
