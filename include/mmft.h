@@ -118,6 +118,15 @@ int mmft_mlp2_rows_bf16(const float* x1, long long ldx1, const int* rows, int n,
                         const void* w2_bf16, const float* b2, const float* mask, long long ldmask, float* hid_out,
                         long long ldhid, float* out, long long ldout, int add_act, int relu_out, int K1, int HD, int D2,
                         const unsigned char* active, int device, void* stream);
+/* MMFT_MATH_BF16: the folded gather of one (net level l - 1, cell level l) pair (mmft_pair_fwd_gather) AND the cell level's
+ * fc_cell_neigh MLP (mmft_mlp2_rows_bf16, forward form, add_act = 1) in ONE launch: h[net rows] = act(pre + mean h[driver]);
+ * A / LSE of the cell rows; h[cell rows] = act(h[cell rows] + W2 relu(W1 A + b1) + b2); hid_out receives the hidden rows.
+ * D = 128 only.  For levels without rows of very high fan-in (those keep the two-kernel form with its workgroup-per-row path). */
+int mmft_level_fwd_bf16(float* h, const float* pre, long long ld, int D, const int* in_net_indptr, const int* in_net_indices,
+                        const int* in_cell_indptr, const int* in_cell_indices, int net_row0, int n_net, const int* cell_rows,
+                        int cell_row0, int n_cell, float* A, float* LSE, const void* w1_bf16, const float* b1,
+                        const void* w2_bf16, const float* b2, float* hid_out, long long ldhid, int relu,
+                        const unsigned char* active, long long alg_bytes, int device, void* stream);
 /* out[c] (+)= sum_r g[idx[r]][c]   (bias gradients); workspace >= mmft_colsum_workspace_bytes */
 long long mmft_colsum_workspace_bytes(int rows, int cols);
 int mmft_colsum(const float* g, const int* idx, long long ld, int rows, int cols, float* out, int accumulate,

@@ -145,6 +145,180 @@ __global__ void __launch_bounds__(512) mlp2_rows_bf16_kernel(Mlp2Bf16Args a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Fused forward LEVEL kernel (bf16 mode): the folded gather of one (net level l - 1, cell level l) pair AND the cell
+// level's Linear-ReLU-Linear in one launch.
+//   blocks [0, cell_tiles):  32 cell rows each - the 512 threads first compute the softmax-weighted fan-in sums A[v]
+//       of their rows (two (row, 4-channel) items per thread, in-neighbours of level l - 1 recomputed from PRE and
+//       their driver's row exactly as pair_fwd_gather does), store A / LSE for the reverse sweep and put the bf16 tile
+//       straight into LDS; then the two MFMA phases of mlp2_rows_bf16_kernel: h[v] = act(h[v] + fc_cell_neigh(A[v]));
+//   blocks [cell_tiles, ...): the net rows of level l - 1: h[u] = act(PRE[u] + mean h[driver]).
+// On the bf16 pipe the MLP of a tile is ~0.3 us of arithmetic, so the chain pays one launch per level pair instead of two.
+// Rows with very many in-edges are walked serially by one thread group here: the caller uses the two-kernel form
+// (pair_fwd_gather with its whole-workgroup path + mlp2_rows_bf16) for levels that have such rows.
+// ------------------------------------------------------------------------------------------------------------------
+struct LevelFwdArgs {
+  float* h;
+  const float* pre;
+  long long ld;
+  const int *in_ptr, *in_idx, *ic_ptr, *ic_idx;
+  int net_row0, n_net;
+  const int* rows;
+  int cell_row0, n_cell;
+  float *A, *LSE;
+  const unsigned short *w1, *w2;
+  const float *b1, *b2;
+  float* hid_out;
+  long long ldhid;
+  int relu;
+  const unsigned char* active;
+  int cell_tiles;
+};
+
+__device__ __forceinline__ f32x4 lv_net_value(const LevelFwdArgs& a, int u, int c) {
+  const int e0 = a.in_ptr[u], e1 = a.in_ptr[u + 1];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int e = e0; e < e1; ++e) acc += *reinterpret_cast<const f32x4*>(a.h + (long long)a.in_idx[e] * a.ld + c);
+  if (e1 > e0) acc = acc * (1.0f / (float)(e1 - e0));
+  acc += *reinterpret_cast<const f32x4*>(a.pre + (long long)u * a.ld + c);
+  if (a.relu) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = acc[j] > 0.f ? acc[j] : 0.f;
+  }
+  return acc;
+}
+
+__global__ void __launch_bounds__(512) level_fwd_bf16_kernel(LevelFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned short xs[L2_BM * L2_XS];
+  __shared__ __attribute__((aligned(16))) unsigned short hs[L2_BM * L2_HS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= a.cell_tiles) {
+    // ---- net rows of level l - 1 (32 float4 groups per row at D = 128)
+    const long long total = (long long)a.n_net * 32;
+    for (long long t = (long long)(blockIdx.x - a.cell_tiles) * 512 + tid; t < total;
+         t += (long long)(gridDim.x - a.cell_tiles) * 512) {
+      const int u = a.net_row0 + (int)(t >> 5), c = ((int)t & 31) * 4;
+      if (a.active && !a.active[u]) continue;
+      *reinterpret_cast<f32x4*>(a.h + (long long)u * a.ld + c) = lv_net_value(a, u, c);
+    }
+    return;
+  }
+  const int m0 = blockIdx.x * L2_BM;
+  auto row_of = [&](int r) -> int { return a.rows ? a.rows[m0 + r] : a.cell_row0 + m0 + r; };
+  auto live_row = [&](int r) -> bool { return m0 + r < a.n_cell && (!a.active || a.active[row_of(r)]); };
+  if (a.active) {
+    int any = 0;
+    if (tid < L2_BM) any = live_row(tid) ? 1 : 0;
+    if (!__syncthreads_or(any)) return;
+  }
+  const int r16 = lane & 15, q = lane >> 4;
+  bf16x8 w1f[2][4], w2f[8];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      w1f[j][ks] = *reinterpret_cast<const bf16x8*>(a.w1 + (long long)(wave * 32 + j * 16 + r16) * L2_K1 + ks * 32 + q * 8);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+    w2f[ks] = *reinterpret_cast<const bf16x8*>(a.w2 + (long long)(wave * 16 + r16) * L2_HD + ks * 32 + q * 8);
+
+  // ---- gather: item = (row r, channel group cg), two items per thread
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int item = tid + it * 512, r = item >> 5, c = (item & 31) * 4;
+    f32x4 av = {0.f, 0.f, 0.f, 0.f};
+    if (live_row(r)) {
+      const int v = row_of(r);
+      const int e0 = a.ic_ptr[v], e1 = a.ic_ptr[v + 1];
+      f32x4 mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sm = {0.f, 0.f, 0.f, 0.f}, acc = sm;
+      for (int e = e0; e < e1; ++e) {
+        const int u = a.ic_idx[e];
+        const f32x4 x = (unsigned)(u - a.net_row0) < (unsigned)a.n_net
+                            ? lv_net_value(a, u, c)
+                            : *reinterpret_cast<const f32x4*>(a.h + (long long)u * a.ld + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float m_new = fmaxf(mx[j], x[j]);
+          float scale = expf(mx[j] - m_new);
+          float pz = expf(x[j] - m_new);
+          sm[j] = sm[j] * scale + pz;
+          acc[j] = acc[j] * scale + pz * x[j];
+          mx[j] = m_new;
+        }
+      }
+      f32x4 lv = {0.f, 0.f, 0.f, 0.f};
+      if (e1 > e0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          av[j] = acc[j] / sm[j];
+          lv[j] = mx[j] + logf(sm[j]);
+        }
+      }
+      *reinterpret_cast<f32x4*>(a.A + (long long)v * a.ld + c) = av;
+      *reinterpret_cast<f32x4*>(a.LSE + (long long)v * a.ld + c) = lv;
+    }
+    const unsigned lo = pack_bf16(av.x, av.y), hi = pack_bf16(av.z, av.w);
+    *reinterpret_cast<unsigned long long*>(xs + r * L2_XS + c) = ((unsigned long long)hi << 32) | lo;
+  }
+  __syncthreads();
+
+  // ---- phase 1 / epilogue 1 / phase 2 / epilogue 2: as mlp2_rows_bf16_kernel (forward form)
+  f32x4 acc1[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    bf16x8 xf[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(xs + (i * 16 + r16) * L2_XS + ks * 32 + q * 8);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[j][ks], xf[i], acc1[i][j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = i * 16 + r16, nn = wave * 32 + j * 16 + q * 4;
+      f32x4 v = acc1[i][j];
+      if (a.b1) v += *reinterpret_cast<const f32x4*>(a.b1 + nn);
+      v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+      v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+      unsigned lo = pack_bf16(v.x, v.y), hi = pack_bf16(v.z, v.w);
+      *reinterpret_cast<unsigned long long*>(hs + m * L2_HS + nn) = ((unsigned long long)hi << 32) | lo;
+      if (a.hid_out && live_row(m)) *reinterpret_cast<f32x4*>(a.hid_out + (long long)row_of(m) * a.ldhid + nn) = v;
+    }
+  __syncthreads();
+  f32x4 acc2[2];
+  acc2[0] = acc2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      bf16x8 hf = *reinterpret_cast<const bf16x8*>(hs + (i * 16 + r16) * L2_HS + ks * 32 + q * 8);
+      acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[ks], hf, acc2[i], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = i * 16 + r16;
+    if (!live_row(m)) continue;
+    const int nn = wave * 16 + q * 4;
+    float* o = a.h + (long long)row_of(m) * a.ld + nn;
+    f32x4 v = acc2[i];
+    if (a.b2) v += *reinterpret_cast<const f32x4*>(a.b2 + nn);
+    v += *reinterpret_cast<const f32x4*>(o);
+    if (a.relu) {
+      v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+      v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(o) = v;
+  }
+}
+
 // dst[r][c] (bf16) = src[r][c], or with transpose dst[c][r] = src[r][c]   (R x C fp32, row stride ld)
 __global__ void __launch_bounds__(256) pack_bf16_kernel(const float* __restrict__ src, long long ld, int R, int C,
                                                         unsigned short* __restrict__ dst, int transpose) {
@@ -194,4 +368,32 @@ extern "C" int mmft_mlp2_rows_bf16(const float* x1, long long ldx1, const int* r
   MMFT_LAUNCH(mask ? "mlp2_rows_bf16_kernel<bwd>" : "mlp2_rows_bf16_kernel<fwd>", fl, by, mlp2_rows_bf16_kernel,
               dim3(cdiv(n, L2_BM)), dim3(512), (hipStream_t)stream, a);
   return check_launch("mlp2_rows_bf16");
+}
+
+extern "C" int mmft_level_fwd_bf16(float* h, const float* pre, long long ld, int D, const int* in_net_indptr,
+                                   const int* in_net_indices, const int* in_cell_indptr, const int* in_cell_indices,
+                                   int net_row0, int n_net, const int* cell_rows, int cell_row0, int n_cell, float* A,
+                                   float* LSE, const void* w1_bf16, const float* b1, const void* w2_bf16, const float* b2,
+                                   float* hid_out, long long ldhid, int relu, const unsigned char* active,
+                                   long long alg_bytes, int device, void* stream) {
+  MMFT_REQUIRE(D == L2_K1, "level_fwd_bf16: D must be %d", L2_K1);
+  MMFT_REQUIRE(n_net >= 0 && n_cell >= 0 && net_row0 >= 0 && cell_row0 >= 0, "level_fwd_bf16: negative row count / offset");
+  if (n_net + n_cell == 0) return MMFT_OK;
+  MMFT_REQUIRE(h && pre && in_net_indptr && in_cell_indptr && (n_cell == 0 || (A && LSE && w1_bf16 && w2_bf16)),
+               "level_fwd_bf16: null pointer");
+  MMFT_REQUIRE(ld >= D && ld % 4 == 0 && aligned16(h) && aligned16(pre) && (!A || aligned16(A)) && (!LSE || aligned16(LSE)) &&
+                   (!w1_bf16 || aligned16(w1_bf16)) && (!w2_bf16 || aligned16(w2_bf16)) && (!b1 || aligned16(b1)) &&
+                   (!b2 || aligned16(b2)) && (!hid_out || (aligned16(hid_out) && ldhid % 4 == 0)),
+               "level_fwd_bf16: operands must be 16-byte aligned");
+  DeviceGuard dg(device);
+  const int tiles = cdiv(n_cell, L2_BM);
+  int net_blocks = cdiv((long long)n_net * 32, 512);
+  if (net_blocks > 1024) net_blocks = 1024;
+  LevelFwdArgs a{h, pre, ld, in_net_indptr, in_net_indices, in_cell_indptr, in_cell_indices, net_row0, n_net, cell_rows,
+                 cell_row0, n_cell, A, LSE, (const unsigned short*)w1_bf16, (const unsigned short*)w2_bf16, b1, b2, hid_out,
+                 ldhid, relu, active, tiles};
+  const double fl = 2.0 * n_cell * ((double)L2_K1 * L2_HD + (double)L2_HD * L2_D2);
+  MMFT_LAUNCH("level_fwd_bf16_kernel", fl, alg_bytes > 0 ? (double)alg_bytes : 0.0, level_fwd_bf16_kernel,
+              dim3(tiles + net_blocks), dim3(512), (hipStream_t)stream, a);
+  return check_launch("level_fwd_bf16");
 }

@@ -228,6 +228,30 @@ def mlp2_rows_bf16(x1, rows, w1p, b1, w2p, b2, out, mask=None, hid_out=None, add
     return out
 
 
+def level_fwd_bf16(h, pre, in_net, in_cell, net_range, cell_rows, A, LSE, w1p, b1, w2p, b2, hid_out, relu=True, active=None,
+                   alg_bytes=0):
+    """Fused forward level kernel of the bf16 mode (mmft_level_fwd_bf16): folded gather + fc_cell_neigh in one launch."""
+    for t, nm in ((h, 'h'), (pre, 'pre'), (A, 'A'), (LSE, 'LSE')):
+        _rows2d(t, nm)
+        if t.shape != h.shape or t.stride(0) != h.stride(0):
+            raise ValueError(f'level_fwd_bf16: {nm} must have the layout of h')
+    N = h.shape[0]
+    if h.shape[1] != 128:
+        raise ValueError('level_fwd_bf16: D = 128 only')
+    _csr(in_net[0], in_net[1], N, 'in_net'); _csr(in_cell[0], in_cell[1], N, 'in_cell')
+    _, nrow0, nn = _rowspec(net_range if net_range is not None else (0, 0), N, 'net_range')
+    ct, crow0, nc = _rowspec(cell_rows, N, 'cell_rows')
+    for t, nm, shape in ((w1p, 'w1p', (256, 128)), (w2p, 'w2p', (128, 256))):
+        if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.bfloat16 and tuple(t.shape) == shape and t.is_contiguous()):
+            raise ValueError(f'level_fwd_bf16: {nm} must be a contiguous bf16 CUDA tensor of shape {shape}')
+    _rows2d(hid_out, 'hid_out')
+    if hid_out.shape != (N, 256):
+        raise ValueError('level_fwd_bf16: hid_out must be [N, 256]')
+    dev, st = lib.stream_args(h)
+    lib.call('mmft_level_fwd_bf16', h, pre, h.stride(0), 128, in_net[0], in_net[1], in_cell[0], in_cell[1], nrow0, nn, ct, crow0,
+             nc, A, LSE, w1p, b1, w2p, b2, hid_out, hid_out.stride(0), int(relu), _active(active, N), int(alg_bytes), dev, st)
+
+
 def _active(active, N):
     if active is None:
         return None

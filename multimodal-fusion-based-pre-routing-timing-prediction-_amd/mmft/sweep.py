@@ -442,6 +442,7 @@ def level_forward(conv, graph, cur_nodes, targets, level_id):
 # wave per SIMD either way, and the software barrier over 252 workgroups (arrival skew of the slowest tile included)
 # costs more than the ~2 us hardware kernel boundary it replaces.  Off by default.
 PERSISTENT_FORWARD = False
+FUSE_LEVEL_FWD = True               # bf16 mode: folded gather + fused MLP of a level pair in one launch (mmft_level_fwd_bf16)
 FOLD_LEVELS = True                  # folded forward chain (one gather per (net, cell) level PAIR) when the graph allows it
 FUSED_FIRST_LAYER_GRADS = True      # mmft_mlp2_first_layer_grads for the *_self MLPs (False: dgrad GEMM + wgrad GEMM)
 
@@ -522,6 +523,12 @@ class SweepFn(torch.autograd.Function):
                 crow = None
                 if has_cell:
                     crow = fold[level_id]['range'] or level_rows[level_id]
+                if has_cell and st.wpack is not None and fold[level_id]['heavy_in'] is None and FUSE_LEVEL_FWD:
+                    # bf16 mode: gather + fc_cell_neigh of the pair in ONE launch
+                    ops.level_fwd_bf16(st.h, st.PRE, in_net, in_cell, fold[net_l]['range'] or (0, 0), crow, st.A, st.LSE,
+                                       st.wpack[0], b1g, st.wpack[1], b2g, st.HN, relu=st.relu, active=st.active,
+                                       alg_bytes=(meta_n['bytes_mean'] if meta_n else 0) + (meta_c['bytes_softmax'] if meta_c else 0))
+                    continue
                 ops.pair_fwd_gather(st.h, st.PRE, in_net, in_cell, fold[net_l]['range'] or (0, 0), crow, st.A, st.LSE,
                                     relu=st.relu, heavy=fold[level_id]['heavy_in'] if has_cell else None, active=st.active,
                                     alg_bytes=(meta_n['bytes_mean'] if meta_n else 0) + (meta_c['bytes_softmax'] if (meta_c and has_cell) else 0))

@@ -237,3 +237,36 @@ def test_training_in_bf16_tracks_fp32(dev):
     assert l16[-1] < 0.5 * l16[0]                                         # it trains
     assert np.abs(l16[-10:].mean() - l32[-10:].mean()) < 0.15 * l32[-10:].mean() + 1e-4
     assert abs(res['bf16'][1] - res['f32'][1]) < 0.2 * res['f32'][1] + 1e-3
+
+
+def test_fused_level_kernel_equals_two_kernel_form(dev):
+    """bf16 mode: mmft_level_fwd_bf16 (folded gather + fc_cell_neigh of a level pair in one launch) against the two-kernel
+    form (mmft_pair_fwd_gather, then mmft_mlp2_rows_bf16): same instruction sequences per row -> bitwise equal embeddings,
+    and the same gradients from the reverse sweep."""
+    from mmft import sweep as S
+    from mmft.synth import synth_design
+    from mmft.train import build_models, DesignBatch
+    designs = [synth_design(N=6000, L=12, tile=32, seed=120 + i, end_frac=0.2) for i in range(2)]
+    b = DesignBatch(designs, dev)
+    pmodel, _ = build_models(map_size=designs[0].map_size, device=dev, seed=8)
+    ends = b.select([np.arange(0, d.num_paths, 3) for d in designs])[0]
+    res = []
+    for fuse in (True, False):
+        S.FUSE_LEVEL_FWD = fuse
+        try:
+            g = b.graph
+            g.ndata['h'] = torch.zeros((b.N, 128), dtype=torch.float32, device=dev)
+            for p in pmodel.gnn.parameters():
+                p.grad = None
+            out = S.sweep_forward_all(pmodel.gnn, g, b.level_nodes, ends)
+            st = g._sweep
+            assert st.wpack is not None and st.fold is not None
+            (out * out).sum().backward()
+            res.append((out.detach().clone(), g.ndata['h'].clone(), st.A.clone(), st.HN.clone(),
+                        {k: p.grad.clone() for k, p in pmodel.gnn.named_parameters() if p.grad is not None}))
+        finally:
+            S.FUSE_LEVEL_FWD = True
+    for x, y in zip(res[0][:4], res[1][:4]):
+        assert torch.equal(x, y)
+    for k in res[1][4]:
+        assert torch.equal(res[0][4][k], res[1][4][k]), k
