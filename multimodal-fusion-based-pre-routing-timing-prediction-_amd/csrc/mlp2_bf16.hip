@@ -188,9 +188,13 @@ __device__ __forceinline__ f32x4 lv_net_value(const LevelFwdArgs& a, int u, int 
   return acc;
 }
 
+// BM rows per tile (16: one gather item per thread, twice as many workgroups - the gather, not the MLP, sets the
+// duration of a level, and it wants the memory-level parallelism; 32: the tile of mlp2_rows_bf16_kernel)
+template <int BM>
 __global__ void __launch_bounds__(512) level_fwd_bf16_kernel(LevelFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned short xs[L2_BM * L2_XS];
-  __shared__ __attribute__((aligned(16))) unsigned short hs[L2_BM * L2_HS];
+  constexpr int RT = BM / 16;
+  __shared__ __attribute__((aligned(16))) unsigned short xs[BM * L2_XS];
+  __shared__ __attribute__((aligned(16))) unsigned short hs[BM * L2_HS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if ((int)blockIdx.x >= a.cell_tiles) {
     // ---- net rows of level l - 1 (32 float4 groups per row at D = 128)
@@ -203,12 +207,12 @@ __global__ void __launch_bounds__(512) level_fwd_bf16_kernel(LevelFwdArgs a) {
     }
     return;
   }
-  const int m0 = blockIdx.x * L2_BM;
+  const int m0 = blockIdx.x * BM;
   auto row_of = [&](int r) -> int { return a.rows ? a.rows[m0 + r] : a.cell_row0 + m0 + r; };
   auto live_row = [&](int r) -> bool { return m0 + r < a.n_cell && (!a.active || a.active[row_of(r)]); };
   if (a.active) {
     int any = 0;
-    if (tid < L2_BM) any = live_row(tid) ? 1 : 0;
+    if (tid < BM) any = live_row(tid) ? 1 : 0;
     if (!__syncthreads_or(any)) return;
   }
   const int r16 = lane & 15, q = lane >> 4;
@@ -224,7 +228,7 @@ __global__ void __launch_bounds__(512) level_fwd_bf16_kernel(LevelFwdArgs a) {
 
   // ---- gather: item = (row r, channel group cg), two items per thread
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < BM / 16; ++it) {
     const int item = tid + it * 512, r = item >> 5, c = (item & 31) * 4;
     f32x4 av = {0.f, 0.f, 0.f, 0.f};
     if (live_row(r)) {
@@ -263,23 +267,23 @@ __global__ void __launch_bounds__(512) level_fwd_bf16_kernel(LevelFwdArgs a) {
   __syncthreads();
 
   // ---- phase 1 / epilogue 1 / phase 2 / epilogue 2: as mlp2_rows_bf16_kernel (forward form)
-  f32x4 acc1[2][2];
+  f32x4 acc1[RT][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    bf16x8 xf[2];
+    bf16x8 xf[RT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(xs + (i * 16 + r16) * L2_XS + ks * 32 + q * 8);
+    for (int i = 0; i < RT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(xs + (i * 16 + r16) * L2_XS + ks * 32 + q * 8);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[j][ks], xf[i], acc1[i][j], 0, 0, 0);
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int m = i * 16 + r16, nn = wave * 32 + j * 16 + q * 4;
@@ -292,18 +296,19 @@ __global__ void __launch_bounds__(512) level_fwd_bf16_kernel(LevelFwdArgs a) {
       if (a.hid_out && live_row(m)) *reinterpret_cast<f32x4*>(a.hid_out + (long long)row_of(m) * a.ldhid + nn) = v;
     }
   __syncthreads();
-  f32x4 acc2[2];
-  acc2[0] = acc2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc2[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RT; ++i) {
       bf16x8 hf = *reinterpret_cast<const bf16x8*>(hs + (i * 16 + r16) * L2_HS + ks * 32 + q * 8);
       acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[ks], hf, acc2[i], 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < RT; ++i) {
     const int m = i * 16 + r16;
     if (!live_row(m)) continue;
     const int nn = wave * 16 + q * 4;
@@ -386,14 +391,15 @@ extern "C" int mmft_level_fwd_bf16(float* h, const float* pre, long long ld, int
                    (!b2 || aligned16(b2)) && (!hid_out || (aligned16(hid_out) && ldhid % 4 == 0)),
                "level_fwd_bf16: operands must be 16-byte aligned");
   DeviceGuard dg(device);
-  const int tiles = cdiv(n_cell, L2_BM);
+  constexpr int LV_BM = 16;
+  const int tiles = cdiv(n_cell, LV_BM);
   int net_blocks = cdiv((long long)n_net * 32, 512);
   if (net_blocks > 1024) net_blocks = 1024;
   LevelFwdArgs a{h, pre, ld, in_net_indptr, in_net_indices, in_cell_indptr, in_cell_indices, net_row0, n_net, cell_rows,
                  cell_row0, n_cell, A, LSE, (const unsigned short*)w1_bf16, (const unsigned short*)w2_bf16, b1, b2, hid_out,
                  ldhid, relu, active, tiles};
   const double fl = 2.0 * n_cell * ((double)L2_K1 * L2_HD + (double)L2_HD * L2_D2);
-  MMFT_LAUNCH("level_fwd_bf16_kernel", fl, alg_bytes > 0 ? (double)alg_bytes : 0.0, level_fwd_bf16_kernel,
+  MMFT_LAUNCH("level_fwd_bf16_kernel", fl, alg_bytes > 0 ? (double)alg_bytes : 0.0, level_fwd_bf16_kernel<LV_BM>,
               dim3(tiles + net_blocks), dim3(512), (hipStream_t)stream, a);
   return check_launch("level_fwd_bf16");
 }
