@@ -243,6 +243,8 @@ def main():
         from mmft.train import GraphedTrainStep
         try:
             stepper = GraphedTrainStep(ts, sample_paths(designs, args.batch_paths, rng), pieces={'auto': None, 'one': False, 'five': True}[args.graph_pieces])
+            if os.environ.get('MMFT_TIME_PIECES') and stepper.pieces:
+                log(f'pieces alone / together (ms): {stepper.time_pieces()}')
             graphed = True
             log('train step captured (%s)' % ('five single-stream HIP graphs on two streams' if stepper.pieces else 'one HIP graph'))
         except Exception as e:                       # noqa: BLE001 - report and keep the eager path

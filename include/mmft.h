@@ -126,7 +126,8 @@ int mmft_level_fwd_bf16(float* h, const float* pre, long long ld, int D, const i
                         const int* in_cell_indptr, const int* in_cell_indices, int net_row0, int n_net, const int* cell_rows,
                         int cell_row0, int n_cell, float* A, float* LSE, const void* w1_bf16, const float* b1,
                         const void* w2_bf16, const float* b2, float* hid_out, long long ldhid, int relu,
-                        const unsigned char* active, long long alg_bytes, int device, void* stream);
+                        const unsigned char* active, const int* in_cell_driver, long long alg_bytes, int device,
+                        void* stream);
 /* out[c] (+)= sum_r g[idx[r]][c]   (bias gradients); workspace >= mmft_colsum_workspace_bytes */
 long long mmft_colsum_workspace_bytes(int rows, int cols);
 int mmft_colsum(const float* g, const int* idx, long long ld, int rows, int cols, float* out, int accumulate,
@@ -216,12 +217,16 @@ int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows,
  *   the net range are recomputed from pre and their driver rows (bitwise the value stored by the first part) instead of
  *   being read from h - so the two levels need no launch boundary between them.  n_cell = 0 gives a plain net level.
  * heavy_rows (optional): exactly the cell rows with more than heavy_thresh in-edges; each is reduced by a whole workgroup
- * (partial online softmaxes merged in a fixed order), the others by one 32-lane thread group walking the edges in series. */
+ * (partial online softmaxes merged in a fixed order), the others by one 32-lane thread group walking the edges in series.
+ * in_cell_driver (optional, one int per cell in-edge, aligned with in_cell_indices): the single driver of the net behind
+ *   the edge (in_net_indices[in_net_indptr[u]] where that net has exactly one in-edge), or a negative value to resolve the
+ *   net through its CSR.  With it the dependent-load chain of an edge is three deep instead of five and four edges are
+ *   requested together; results are bitwise those of the serial form. */
 int mmft_pair_fwd_gather(float* h, const float* pre, long long ld, int D, const int* in_net_indptr,
                          const int* in_net_indices, const int* in_cell_indptr, const int* in_cell_indices, int net_row0,
                          int n_net, const int* cell_rows, int cell_row0, int n_cell, float* A, float* LSE, long long lda,
                          int relu, const int* heavy_rows, int nheavy, int heavy_thresh, const unsigned char* active,
-                         long long alg_bytes, int device, void* stream);
+                         const int* in_cell_driver, long long alg_bytes, int device, void* stream);
 /* own_mask (may be NULL): per-node flag telling whether G[v] already holds a gradient of its own (a sampled endpoint,
  * src/model.py:213); rows without the flag start from zero, so G needs no 4*N*D-byte fill per step.
  * mmft_target_rows_begin zeroes the G rows of the endpoints idx[0..n) and sets their flags (the scatter-add of the
@@ -432,6 +437,18 @@ int mmft_path_mask_fill(const int* paths, const int* lens, int npaths, int maxle
 long long mmft_minmax_workspace_bytes(int n, int ncol);
 int mmft_minmax_normalize(float* feat, long long ld, int n, int C, int start_col, float* workspace,
                           long long workspace_bytes, int device, void* stream);
+
+/* ---- streams with a share of the compute units -----------------------------------------------------------------------
+ * The step's two independent branches (netlist sweep: src/model.py:176-214; layout U-Net: src/Unet.py:85-113) are
+ * replayed on two HIP streams.  mmft_stream_create_cu_mask creates a stream whose kernels may only occupy the CUs whose
+ * bit is set in mask[0 .. nwords) (bit i of word i / 32; hipExtStreamCreateWithCUMask); *stream_out receives the
+ * hipStream_t as an integer (torch.cuda.ExternalStream takes it).  mmft_device_cu_count: CUs of the device, -1 on error. */
+int mmft_stream_create_cu_mask(int device, const unsigned int* mask, int nwords, long long* stream_out);
+int mmft_stream_destroy(long long stream);
+int mmft_device_cu_count(int device);
+/* Diagnostic for the mask layout: n_wg workgroups of 1024 threads, each holding its CU for spin_ticks of the 100 MHz wall
+ * clock; out[i] = (XCC id << 16) | (HW_ID & 0xffff) of workgroup i (HW_ID: cu 11:8, sh 12, se 15:13). */
+int mmft_debug_cu_census(unsigned int* out, int n_wg, int spin_ticks, int device, void* stream);
 
 #ifdef __cplusplus
 }

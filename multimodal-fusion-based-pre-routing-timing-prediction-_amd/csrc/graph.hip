@@ -10,6 +10,7 @@
 // ~2), so the per-thread edge loop is short; heavy-tailed out-degrees in the reverse sweep are the
 // known skew.
 #include "common.h"
+#include "fold_gather.h"
 
 namespace mmft {
 
@@ -217,49 +218,15 @@ __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
 // thread groups stride over the edges with an online softmax each and their (max, sum, weighted sum) triples are merged
 // in a fixed order.
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ f32x4 net_node_value(const float* __restrict__ h, const float* __restrict__ PRE, long long ld,
-                                                int u, int c, const int* __restrict__ in_ptr,
-                                                const int* __restrict__ in_idx, int relu) {
-  const int e0 = in_ptr[u], e1 = in_ptr[u + 1];
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int e = e0; e < e1; ++e) acc += ld4(h + (long long)in_idx[e] * ld + c);
-  if (e1 > e0) acc = acc * (1.0f / (float)(e1 - e0));
-  acc += ld4(PRE + (long long)u * ld + c);
-  if (relu) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = acc[j] > 0.f ? acc[j] : 0.f;
-  }
-  return acc;
-}
-
-struct SoftAcc {
-  f32x4 mx, s, acc;
-  __device__ __forceinline__ void init() {
-    mx = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    s = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc = s;
-  }
-  __device__ __forceinline__ void add(f32x4 x) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float m_new = fmaxf(mx[j], x[j]);
-      float scale = expf(mx[j] - m_new);
-      float p = expf(x[j] - m_new);
-      s[j] = s[j] * scale + p;
-      acc[j] = acc[j] * scale + p * x[j];
-      mx[j] = m_new;
-    }
-  }
-};
-
 __global__ void __launch_bounds__(256) pair_fwd_gather_kernel(
     float* __restrict__ h, const float* __restrict__ PRE, long long ld, int D, const int* __restrict__ in_ptr,
     const int* __restrict__ in_idx, const int* __restrict__ ic_ptr, const int* __restrict__ ic_idx, int net_row0, int n_net,
     const int* __restrict__ rows, int cell_row0, int n_cell, float* __restrict__ A, float* __restrict__ LSE, long long lda,
     int relu, const int* __restrict__ heavy, int nheavy, int light_blocks, int heavy_thresh,
-    const unsigned char* __restrict__ active) {
+    const unsigned char* __restrict__ active, const int* __restrict__ ic_drv) {
   __shared__ f32x4 pm[8][64], ps[8][64], pa[8][64];
   const int groups = D >> 2;
+  const FoldSrc fs{h, PRE, ld, in_ptr, in_idx, ic_idx, ic_drv, net_row0, n_net, relu};
   if ((int)blockIdx.x >= light_blocks) {
     const int tgs = 256 / groups, act = tgs < 8 ? tgs : 8;
     const int tg = threadIdx.x / groups, c = (threadIdx.x - tg * groups) * 4;
@@ -270,11 +237,7 @@ __global__ void __launch_bounds__(256) pair_fwd_gather_kernel(
       if (tg < act) {
         SoftAcc sa;
         sa.init();
-        for (int e = e0 + tg; e < e1; e += act) {
-          const int u = ic_idx[e];
-          sa.add((unsigned)(u - net_row0) < (unsigned)n_net ? net_node_value(h, PRE, ld, u, c, in_ptr, in_idx, relu)
-                                                            : ld4(h + (long long)u * ld + c));
-        }
+        fold_gather_edges(fs, e0 + tg, e1, act, c, sa);
         pm[tg][c >> 2] = sa.mx; ps[tg][c >> 2] = sa.s; pa[tg][c >> 2] = sa.acc;
       }
       __syncthreads();
@@ -310,7 +273,7 @@ __global__ void __launch_bounds__(256) pair_fwd_gather_kernel(
     if (i < n_net) {                                         // part A
       const int u = net_row0 + i;
       if (active && !active[u]) continue;
-      st4(h + (long long)u * ld + c, net_node_value(h, PRE, ld, u, c, in_ptr, in_idx, relu));
+      st4(h + (long long)u * ld + c, fold_net_value(fs, u, c));
       continue;
     }
     i -= n_net;                                              // part B
@@ -320,11 +283,7 @@ __global__ void __launch_bounds__(256) pair_fwd_gather_kernel(
     if (active && !active[v]) continue;
     SoftAcc sa;
     sa.init();
-    for (int e = e0; e < e1; ++e) {
-      const int u = ic_idx[e];
-      sa.add((unsigned)(u - net_row0) < (unsigned)n_net ? net_node_value(h, PRE, ld, u, c, in_ptr, in_idx, relu)
-                                                        : ld4(h + (long long)u * ld + c));
-    }
+    fold_gather_edges(fs, e0, e1, 1, c, sa);
     f32x4 a = {0.f, 0.f, 0.f, 0.f}, l = {0.f, 0.f, 0.f, 0.f};
     if (e1 > e0) {
 #pragma unroll
@@ -714,7 +673,7 @@ int mmft_pair_fwd_gather(float* h, const float* pre, long long ld, int D, const 
                          const int* in_net_indices, const int* in_cell_indptr, const int* in_cell_indices, int net_row0,
                          int n_net, const int* cell_rows, int cell_row0, int n_cell, float* A, float* LSE, long long lda,
                          int relu, const int* heavy_rows, int nheavy, int heavy_thresh, const unsigned char* active,
-                         long long alg_bytes, int device, void* stream) {
+                         const int* in_cell_driver, long long alg_bytes, int device, void* stream) {
   const int n = n_net + n_cell;
   CHECK_ROWS("pair_fwd_gather");
   MMFT_REQUIRE(n_net >= 0 && n_cell >= 0 && net_row0 >= 0 && cell_row0 >= 0, "pair_fwd_gather: negative row count / offset");
@@ -731,7 +690,7 @@ int mmft_pair_fwd_gather(float* h, const float* pre, long long ld, int D, const 
   MMFT_LAUNCH("pair_fwd_gather_kernel", 0.0, alg_bytes > 0 ? (double)alg_bytes : 3.0 * 4.0 * n * D, pair_fwd_gather_kernel,
               dim3(light + hb), dim3(256), (hipStream_t)stream, h, pre, ld, D, in_net_indptr, in_net_indices, in_cell_indptr,
               in_cell_indices, net_row0, n_net, cell_rows, cell_row0, n_cell, A, LSE, lda, relu,
-              nheavy ? heavy_rows : nullptr, nheavy, light, heavy_thresh, active);
+              nheavy ? heavy_rows : nullptr, nheavy, light, heavy_thresh, active, in_cell_driver);
   return check_launch("pair_fwd_gather");
 }
 

@@ -14,6 +14,7 @@
 //   * 8 waves per 32-row tile: wave w owns hidden columns [32w, 32w + 32) and output columns [16w, 16w + 16).
 // The reverse form (weights_kmajor in the fp32 kernel) is the same kernel fed with the transposed packs.
 #include "gemm_bf16.h"
+#include "fold_gather.h"
 
 namespace mmft {
 
@@ -161,7 +162,7 @@ struct LevelFwdArgs {
   float* h;
   const float* pre;
   long long ld;
-  const int *in_ptr, *in_idx, *ic_ptr, *ic_idx;
+  const int *in_ptr, *in_idx, *ic_ptr, *ic_idx, *ic_drv;
   int net_row0, n_net;
   const int* rows;
   int cell_row0, n_cell;
@@ -175,19 +176,6 @@ struct LevelFwdArgs {
   int cell_tiles;
 };
 
-__device__ __forceinline__ f32x4 lv_net_value(const LevelFwdArgs& a, int u, int c) {
-  const int e0 = a.in_ptr[u], e1 = a.in_ptr[u + 1];
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int e = e0; e < e1; ++e) acc += *reinterpret_cast<const f32x4*>(a.h + (long long)a.in_idx[e] * a.ld + c);
-  if (e1 > e0) acc = acc * (1.0f / (float)(e1 - e0));
-  acc += *reinterpret_cast<const f32x4*>(a.pre + (long long)u * a.ld + c);
-  if (a.relu) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = acc[j] > 0.f ? acc[j] : 0.f;
-  }
-  return acc;
-}
-
 // BM rows per tile (16: one gather item per thread, twice as many workgroups - the gather, not the MLP, sets the
 // duration of a level, and it wants the memory-level parallelism; 32: the tile of mlp2_rows_bf16_kernel)
 template <int BM>
@@ -196,6 +184,7 @@ __global__ void __launch_bounds__(512) level_fwd_bf16_kernel(LevelFwdArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned short xs[BM * L2_XS];
   __shared__ __attribute__((aligned(16))) unsigned short hs[BM * L2_HS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const FoldSrc fs{a.h, a.pre, a.ld, a.in_ptr, a.in_idx, a.ic_idx, a.ic_drv, a.net_row0, a.n_net, a.relu};
   if ((int)blockIdx.x >= a.cell_tiles) {
     // ---- net rows of level l - 1 (32 float4 groups per row at D = 128)
     const long long total = (long long)a.n_net * 32;
@@ -203,7 +192,7 @@ __global__ void __launch_bounds__(512) level_fwd_bf16_kernel(LevelFwdArgs a) {
          t += (long long)(gridDim.x - a.cell_tiles) * 512) {
       const int u = a.net_row0 + (int)(t >> 5), c = ((int)t & 31) * 4;
       if (a.active && !a.active[u]) continue;
-      *reinterpret_cast<f32x4*>(a.h + (long long)u * a.ld + c) = lv_net_value(a, u, c);
+      *reinterpret_cast<f32x4*>(a.h + (long long)u * a.ld + c) = fold_net_value(fs, u, c);
     }
     return;
   }
@@ -222,9 +211,6 @@ __global__ void __launch_bounds__(512) level_fwd_bf16_kernel(LevelFwdArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
       w1f[j][ks] = *reinterpret_cast<const bf16x8*>(a.w1 + (long long)(wave * 32 + j * 16 + r16) * L2_K1 + ks * 32 + q * 8);
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks)
-    w2f[ks] = *reinterpret_cast<const bf16x8*>(a.w2 + (long long)(wave * 16 + r16) * L2_HD + ks * 32 + q * 8);
 
   // ---- gather: item = (row r, channel group cg), two items per thread
 #pragma unroll
@@ -234,28 +220,15 @@ __global__ void __launch_bounds__(512) level_fwd_bf16_kernel(LevelFwdArgs a) {
     if (live_row(r)) {
       const int v = row_of(r);
       const int e0 = a.ic_ptr[v], e1 = a.ic_ptr[v + 1];
-      f32x4 mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sm = {0.f, 0.f, 0.f, 0.f}, acc = sm;
-      for (int e = e0; e < e1; ++e) {
-        const int u = a.ic_idx[e];
-        const f32x4 x = (unsigned)(u - a.net_row0) < (unsigned)a.n_net
-                            ? lv_net_value(a, u, c)
-                            : *reinterpret_cast<const f32x4*>(a.h + (long long)u * a.ld + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float m_new = fmaxf(mx[j], x[j]);
-          float scale = expf(mx[j] - m_new);
-          float pz = expf(x[j] - m_new);
-          sm[j] = sm[j] * scale + pz;
-          acc[j] = acc[j] * scale + pz * x[j];
-          mx[j] = m_new;
-        }
-      }
+      SoftAcc sa;
+      sa.init();
+      fold_gather_edges(fs, e0, e1, 1, c, sa);
       f32x4 lv = {0.f, 0.f, 0.f, 0.f};
       if (e1 > e0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          av[j] = acc[j] / sm[j];
-          lv[j] = mx[j] + logf(sm[j]);
+          av[j] = sa.acc[j] / sa.s[j];
+          lv[j] = sa.mx[j] + logf(sa.s[j]);
         }
       }
       *reinterpret_cast<f32x4*>(a.A + (long long)v * a.ld + c) = av;
@@ -264,6 +237,10 @@ __global__ void __launch_bounds__(512) level_fwd_bf16_kernel(LevelFwdArgs a) {
     const unsigned lo = pack_bf16(av.x, av.y), hi = pack_bf16(av.z, av.w);
     *reinterpret_cast<unsigned long long*>(xs + r * L2_XS + c) = ((unsigned long long)hi << 32) | lo;
   }
+  // the second layer's fragments are requested only now: held across the gather they cost 32 registers and a wave of occupancy
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+    w2f[ks] = *reinterpret_cast<const bf16x8*>(a.w2 + (long long)(wave * 16 + r16) * L2_HD + ks * 32 + q * 8);
   __syncthreads();
 
   // ---- phase 1 / epilogue 1 / phase 2 / epilogue 2: as mlp2_rows_bf16_kernel (forward form)
@@ -380,7 +357,7 @@ extern "C" int mmft_level_fwd_bf16(float* h, const float* pre, long long ld, int
                                    int net_row0, int n_net, const int* cell_rows, int cell_row0, int n_cell, float* A,
                                    float* LSE, const void* w1_bf16, const float* b1, const void* w2_bf16, const float* b2,
                                    float* hid_out, long long ldhid, int relu, const unsigned char* active,
-                                   long long alg_bytes, int device, void* stream) {
+                                   const int* in_cell_driver, long long alg_bytes, int device, void* stream) {
   MMFT_REQUIRE(D == L2_K1, "level_fwd_bf16: D must be %d", L2_K1);
   MMFT_REQUIRE(n_net >= 0 && n_cell >= 0 && net_row0 >= 0 && cell_row0 >= 0, "level_fwd_bf16: negative row count / offset");
   if (n_net + n_cell == 0) return MMFT_OK;
@@ -395,7 +372,7 @@ extern "C" int mmft_level_fwd_bf16(float* h, const float* pre, long long ld, int
   const int tiles = cdiv(n_cell, LV_BM);
   int net_blocks = cdiv((long long)n_net * 32, 512);
   if (net_blocks > 1024) net_blocks = 1024;
-  LevelFwdArgs a{h, pre, ld, in_net_indptr, in_net_indices, in_cell_indptr, in_cell_indices, net_row0, n_net, cell_rows,
+  LevelFwdArgs a{h, pre, ld, in_net_indptr, in_net_indices, in_cell_indptr, in_cell_indices, in_cell_driver, net_row0, n_net, cell_rows,
                  cell_row0, n_cell, A, LSE, (const unsigned short*)w1_bf16, (const unsigned short*)w2_bf16, b1, b2, hid_out,
                  ldhid, relu, active, tiles};
   const double fl = 2.0 * n_cell * ((double)L2_K1 * L2_HD + (double)L2_HD * L2_D2);

@@ -113,6 +113,41 @@ def workspace(device, nbytes):
     return buf
 
 
+def cu_count(device=None):
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index or 0
+    n = query('mmft_device_cu_count', dev)
+    if n <= 0:
+        raise RuntimeError('mmft_device_cu_count failed')
+    return n
+
+
+class MaskedStream:
+    """A HIP stream whose kernels only occupy the given compute units (mmft_stream_create_cu_mask), wrapped for torch:
+    `.stream` is a torch.cuda.ExternalStream.  cus: iterable of CU bit positions."""
+
+    def __init__(self, device, cus):
+        import numpy as np
+        dev = torch.device(device)
+        self.index = dev.index if dev.index is not None else torch.cuda.current_device()
+        n = cu_count(self.index)
+        cus = sorted(set(int(c) for c in cus))
+        if not cus or cus[0] < 0 or cus[-1] >= n:
+            raise ValueError(f'MaskedStream: CU positions must lie in [0, {n})')
+        words = np.zeros((n + 31) // 32, dtype=np.uint32)
+        for c in cus:
+            words[c // 32] |= np.uint32(1 << (c % 32))
+        out = ctypes.c_longlong(0)
+        call('mmft_stream_create_cu_mask', self.index, words.ctypes.data, int(words.shape[0]), ctypes.addressof(out))
+        self.handle = int(out.value)
+        self.cus = cus
+        self.stream = torch.cuda.ExternalStream(self.handle, device=dev)
+
+    def close(self):
+        if self.handle:
+            call('mmft_stream_destroy', self.handle)
+            self.handle = 0
+
+
 MATH_MODES = {'f32': 0, 'bf16': 1}
 
 

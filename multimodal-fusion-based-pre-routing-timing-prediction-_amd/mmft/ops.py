@@ -229,7 +229,7 @@ def mlp2_rows_bf16(x1, rows, w1p, b1, w2p, b2, out, mask=None, hid_out=None, add
 
 
 def level_fwd_bf16(h, pre, in_net, in_cell, net_range, cell_rows, A, LSE, w1p, b1, w2p, b2, hid_out, relu=True, active=None,
-                   alg_bytes=0):
+                   alg_bytes=0, in_cell_driver=None):
     """Fused forward level kernel of the bf16 mode (mmft_level_fwd_bf16): folded gather + fc_cell_neigh in one launch."""
     for t, nm in ((h, 'h'), (pre, 'pre'), (A, 'A'), (LSE, 'LSE')):
         _rows2d(t, nm)
@@ -249,7 +249,17 @@ def level_fwd_bf16(h, pre, in_net, in_cell, net_range, cell_rows, A, LSE, w1p, b
         raise ValueError('level_fwd_bf16: hid_out must be [N, 256]')
     dev, st = lib.stream_args(h)
     lib.call('mmft_level_fwd_bf16', h, pre, h.stride(0), 128, in_net[0], in_net[1], in_cell[0], in_cell[1], nrow0, nn, ct, crow0,
-             nc, A, LSE, w1p, b1, w2p, b2, hid_out, hid_out.stride(0), int(relu), _active(active, N), int(alg_bytes), dev, st)
+             nc, A, LSE, w1p, b1, w2p, b2, hid_out, hid_out.stride(0), int(relu), _active(active, N),
+             _edge_drivers(in_cell_driver, in_cell[1]), int(alg_bytes), dev, st)
+
+
+def _edge_drivers(drv, indices):
+    if drv is None:
+        return None
+    _idx(drv, 'in_cell_driver')
+    if drv.numel() != indices.numel():
+        raise ValueError('in_cell_driver: one entry per cell in-edge expected')
+    return drv
 
 
 def _active(active, N):
@@ -430,7 +440,7 @@ def level_bwd_pull(G, h, rows, out_net, out_net_w, out_cell, A, LSE, DA, relu=Tr
 
 
 def pair_fwd_gather(h, pre, in_net, in_cell, net_range, cell_rows, A, LSE, relu=True, heavy=None, heavy_thresh=PAIR_HEAVY_IN,
-                    alg_bytes=0, active=None):
+                    alg_bytes=0, active=None, in_cell_driver=None):
     """Folded forward gather of one (net level, cell level) pair: see mmft_pair_fwd_gather in include/mmft.h.
     net_range = (row0, n); cell_rows = int32 tensor | (row0, n) | None (no cell level)."""
     _rows2d(h, 'h'); _rows2d(pre, 'pre')
@@ -451,7 +461,8 @@ def pair_fwd_gather(h, pre, in_net, in_cell, net_range, cell_rows, A, LSE, relu=
     dev, st = lib.stream_args(h)
     lib.call('mmft_pair_fwd_gather', h, pre, h.stride(0), h.shape[1], in_net[0], in_net[1], in_cell[0], in_cell[1], nrow0, nn,
              ct, crow0, nc, A if nc else None, LSE if nc else None, A.stride(0) if nc else h.stride(0), int(relu), heavy,
-             heavy.numel() if heavy is not None else 0, int(heavy_thresh), _active(active, N), int(alg_bytes), dev, st)
+             heavy.numel() if heavy is not None else 0, int(heavy_thresh), _active(active, N),
+             _edge_drivers(in_cell_driver, in_cell[1]), int(alg_bytes), dev, st)
 
 
 ATTN_SLOPE = 0.01          # F.leaky_relu default (src/model.py:136)

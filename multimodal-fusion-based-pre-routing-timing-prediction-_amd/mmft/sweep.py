@@ -442,6 +442,7 @@ def level_forward(conv, graph, cur_nodes, targets, level_id):
 # wave per SIMD either way, and the software barrier over 252 workgroups (arrival skew of the slowest tile included)
 # costs more than the ~2 us hardware kernel boundary it replaces.  Off by default.
 PERSISTENT_FORWARD = False
+EDGE_DRIVERS = True                 # folded gather: per-edge driver table (3-deep load chain, four edges in flight)
 FUSE_LEVEL_FWD = True               # bf16 mode: folded gather + fused MLP of a level pair in one launch (mmft_level_fwd_bf16)
 FOLD_LEVELS = True                  # folded forward chain (one gather per (net, cell) level PAIR) when the graph allows it
 FUSED_FIRST_LAYER_GRADS = True      # mmft_mlp2_first_layer_grads for the *_self MLPs (False: dgrad GEMM + wgrad GEMM)
@@ -513,6 +514,7 @@ class SweepFn(torch.autograd.Function):
         if fold is not None and not persistent:
             # folded chain: one gather launch per (net level l - 1, cell level l) pair + the fused MLP of the cell level
             L = len(level_rows)
+            drv = g.cell_edge_drivers() if EDGE_DRIVERS else None
             for level_id in range(2, L + 1, 2):
                 net_l = level_id - 1
                 has_cell = level_id < L and level_rows[level_id].numel() > 0
@@ -526,11 +528,12 @@ class SweepFn(torch.autograd.Function):
                 if has_cell and st.wpack is not None and fold[level_id]['heavy_in'] is None and FUSE_LEVEL_FWD:
                     # bf16 mode: gather + fc_cell_neigh of the pair in ONE launch
                     ops.level_fwd_bf16(st.h, st.PRE, in_net, in_cell, fold[net_l]['range'] or (0, 0), crow, st.A, st.LSE,
-                                       st.wpack[0], b1g, st.wpack[1], b2g, st.HN, relu=st.relu, active=st.active,
+                                       st.wpack[0], b1g, st.wpack[1], b2g, st.HN, relu=st.relu, active=st.active, in_cell_driver=drv,
                                        alg_bytes=(meta_n['bytes_mean'] if meta_n else 0) + (meta_c['bytes_softmax'] if meta_c else 0))
                     continue
                 ops.pair_fwd_gather(st.h, st.PRE, in_net, in_cell, fold[net_l]['range'] or (0, 0), crow, st.A, st.LSE,
                                     relu=st.relu, heavy=fold[level_id]['heavy_in'] if has_cell else None, active=st.active,
+                                    in_cell_driver=drv,
                                     alg_bytes=(meta_n['bytes_mean'] if meta_n else 0) + (meta_c['bytes_softmax'] if (meta_c and has_cell) else 0))
                 if has_cell:
                     _cell_neigh_fwd(st, level_rows[level_id], w1g, b1g, w2g, b2g, act)

@@ -32,6 +32,20 @@ def main(path, verbose=False):
         ks = [r for r in step if r['Queue_Id'] == q]
         print(f'queue {q}: {len(ks)} kernels, first start {(ks[0]["s"] - t0) / 1e3:.0f} us, last end {(ks[-1]["e"] - t0) / 1e3:.0f} us, '
               f'busy {sum(r["e"] - r["s"] for r in ks) / 1e3:.0f} us')
+    # per-kernel totals INSIDE the replayed step (no per-launch profiling floor), and the idle time in front of each kernel
+    short = lambda n: n.replace('void mmft::', '').replace('mmft::', '').split('(')[0][:70]
+    agg = collections.defaultdict(lambda: [0, 0, 0])
+    busy_until = step[0]['s']
+    for r in step:
+        a_ = agg[short(r['Kernel_Name'])]
+        a_[0] += 1
+        a_[1] += r['e'] - r['s']
+        if r['s'] > busy_until:
+            a_[2] += r['s'] - busy_until
+        busy_until = max(busy_until, r['e'])
+    print(f'{"kernel":72s} {"n":>4s} {"total us":>9s} {"avg us":>8s} {"idle before, us":>16s}')
+    for name, (n, tot, idle) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f'{name:72s} {n:4d} {tot / 1e3:9.1f} {tot / 1e3 / n:8.2f} {idle / 1e3:16.1f}')
     if verbose:
         prev, start, cnt = None, None, 0
         for r in step:
