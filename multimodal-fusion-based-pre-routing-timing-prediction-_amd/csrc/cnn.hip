@@ -4,6 +4,7 @@
 // Replaces the torch modules inside the reference's src/Unet.py:8-119 and LayoutNet (src/model.py:216-247).
 #include "gemm_engine.h"
 #include "conv_direct.h"
+#include "conv_wgrad_narrow.h"
 
 namespace mmft {
 
@@ -584,7 +585,12 @@ static int conv_wgrad_splits(int Nimg, int H, int W, int Ci, int Co, int KH, int
 
 long long mmft_conv2d_wgrad_workspace_bytes(int Nimg, int H, int W, int Ci, int Co, int KH, int KW) {
   int s = conv_wgrad_splits(Nimg, H, W, Ci, Co, KH, KW);
-  return s > 1 ? (long long)s * Co * KH * KW * Ci * 4 : 0;
+  long long need = s > 1 ? (long long)s * Co * KH * KW * Ci * 4 : 0;
+  if (conv_wgrad_narrow_shape_ok<WGN_TH>(H, W, Ci, Co, KH, KW, (KH - 1) / 2)) {      // either math mode may be active later
+    long long narrow = (long long)conv_wgrad_narrow_grid(Nimg, H, W, Ci) * Co * 9 * Ci * 4;
+    if (narrow > need) need = narrow;
+  }
+  return need;
 }
 
 int mmft_conv2d_wgrad(const float* x, const float* dy, float* dw, int Nimg, int H, int W, int Ci, int Co, int KH, int KW,
@@ -594,6 +600,13 @@ int mmft_conv2d_wgrad(const float* x, const float* dy, float* dw, int Nimg, int 
   DeviceGuard dg(device);
   hipStream_t st = (hipStream_t)stream;
   int M = Co, N = KH * KW * Ci, K = Nimg * H * W;
+  if (conv_wgrad_narrow_ok(H, W, Ci, Co, KH, KW, pad) && aligned16(x) && aligned16(dy) && aligned16(dw)) {
+    const int grid = conv_wgrad_narrow_grid(Nimg, H, W, Ci);
+    MMFT_REQUIRE(workspace && workspace_bytes >= (long long)grid * M * N * 4, "conv2d_wgrad: workspace too small");
+    int rc = conv_wgrad_narrow_launch(x, dy, workspace, Nimg, H, W, Ci, Co, grid, st);
+    if (rc) return rc;
+    return launch_slab_reduce(workspace, grid, (long long)M * N, dw, 0, st);
+  }
   int splits = conv_wgrad_splits(Nimg, H, W, Ci, Co, KH, KW);
   long long need = splits > 1 ? (long long)splits * M * N * 4 : 0;
   MMFT_REQUIRE(splits <= 1 || (workspace && workspace_bytes >= need), "conv2d_wgrad: workspace too small");
