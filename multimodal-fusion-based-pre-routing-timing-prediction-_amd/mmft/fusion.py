@@ -125,19 +125,36 @@ class MaskedPathMap:
     def __init__(self, masks, paths, feat_map, f_off=None, first=None, next_=None):
         self.masks = masks
         dev = feat_map.device
-        if first is None:                                  # small ad-hoc batches: derive the links on the host
-            ph = paths.detach().cpu().numpy() if torch.is_tensor(paths) else np.asarray(paths)
-            f_h, n_h = batch_links(ph, masks.num_paths)
-            first, next_ = torch.from_numpy(f_h).to(dev), torch.from_numpy(n_h).to(dev)
-            if f_off is None and masks.B > 1:
-                f_off = torch.from_numpy((masks.row_design[ph] * masks.P).astype(np.int32)).to(dev)
         if not torch.is_tensor(paths):
-            paths = torch.tensor(paths, dtype=torch.int32)
+            paths = torch.as_tensor(np.asarray(paths), dtype=torch.int32)
         self.paths = paths.to(torch.int32).to(dev).contiguous()
-        self.f_off, self.first, self.next = f_off, first, next_
+        if f_off is None and masks.B > 1:
+            # feature-map offset of each row's design, looked up on the device (no host round trip per level call)
+            rd = masks.__dict__.get('_row_off_dev')
+            if rd is None or rd.device != dev:
+                rd = masks.__dict__['_row_off_dev'] = torch.from_numpy((masks.row_design * masks.P).astype(np.int32)).to(dev)
+            f_off = rd[self.paths.long()]
+        self.f_off, self._first, self._next = f_off, first, next_
         self.feat_map = feat_map
         if feat_map.numel() != masks.B * masks.P:
             raise ValueError(f'feat_map has {feat_map.numel()} elements, masks expect {masks.B} x {masks.P}')
+
+    def _links(self):
+        """first / next chains over the rows that share a path (only the backward kernels read them).  Small ad-hoc
+        batches derive them on the host - one device-to-host copy of the row list, paid at the first backward use."""
+        if self._first is None:
+            f_h, n_h = batch_links(self.paths.detach().cpu().numpy(), self.masks.num_paths)
+            dev = self.paths.device
+            self._first, self._next = torch.from_numpy(f_h).to(dev), torch.from_numpy(n_h).to(dev)
+        return self._first, self._next
+
+    @property
+    def first(self):
+        return self._links()[0]
+
+    @property
+    def next(self):
+        return self._links()[1]
 
     def __len__(self):
         return self.paths.numel()

@@ -123,6 +123,100 @@ class LayoutNet(nn.Module):
         return y[0] if squeeze else y
 
 
+# Deferred fusion head of the per-level (drop-in) loop.  The reference calls the model once per level and sums the
+# losses (src/train.py:490-522); executed literally, every level call carries its own head backward - 31 masked-projection
+# gradients over the full 2.3 M-entry weight, ~20 small launches each - and the step takes five times the whole-sweep one.
+# Nothing forces that order: the head's parameters and the feature map are the same for every level.  So a level call
+# computes its predictions WITHOUT an autograd graph (HeadLevelFn) and hangs them off a per-step root node; its backward
+# only stores the incoming gradient.  The engine runs the root's backward after every level node, and there the head of
+# ALL levels is recomputed as one batch (the whole-sweep kernels: one masked projection, one mlp_fuse) and differentiated
+# once.  The gradient of the endpoint embeddings is scattered into the sweep's gradient buffer directly - the root takes
+# the speculative sweep's token as an input, so the reverse sweep (SweepFn.backward) is ordered after it.
+LAZY_HEAD = True
+
+
+class _HeadBatch:
+    def __init__(self, model, graph, st, feat_map, masks):
+        self.model, self.graph, self.st, self.feat_map, self.masks = model, graph, st, feat_map, masks
+        self.tix, self.paths, self.level_th, self.grads = [], [], [], []
+        self.token = HeadRootFn.apply(st.spec_token, feat_map, self)
+        # mlp_alpha of every level in one launch pair: the level-id tensors of the previous step's calls are tried first
+        # (the reference loop and TrainStep pass the same objects every step); a call with another tensor computes its own
+        prev = graph.__dict__.get('_head_level_th')
+        self.alpha_src, self.alpha = None, None
+        if prev and all(t.numel() == 1 for t in prev):
+            with th.no_grad():
+                self.alpha_src = prev
+                self.alpha = model.mlp_alpha(th.cat([t.reshape(1, 1) for t in prev]).to(th.float32))
+
+    def alpha_of(self, slot, level_id_th):
+        src = self.alpha_src
+        if src is not None and slot < len(src) and src[slot] is level_id_th:
+            return self.alpha[slot]
+        return self.model.mlp_alpha(level_id_th).reshape(-1)
+
+    def backward(self):
+        from mmft import ops
+        st, m = self.st, self.model
+        slots = [i for i, g in enumerate(self.grads) if g is not None]
+        if not slots:
+            return None
+        counts = [int(self.tix[i].numel()) for i in slots]
+        tix = th.cat([self.tix[i] for i in slots])
+        paths = th.cat([self.paths[i] for i in slots])
+        gr = th.cat([self.grads[i] for i in slots])
+        lvt = th.cat([self.level_th[i].reshape(1, -1) for i in slots]).to(th.float32)
+        slot_of_row = th.repeat_interleave(th.arange(len(slots), dtype=th.int32), th.tensor(counts)).to(tix.device)
+        with th.enable_grad():
+            h_all = ops.gather_rows(st.h, tix).requires_grad_(True)
+            feat = self.feat_map.detach().requires_grad_(True)
+            pm = MaskedPathMap(self.masks, paths, feat)
+            h_cnn = m._fcn(pm)
+            h_global = MF.gather_rows(m.mlp_alpha(lvt), slot_of_row)
+            hats = m.mlp_fuse(th.cat((h_all, h_cnn, h_global), 1)).squeeze(-1)
+            params = [p for p in list(m.fcn.parameters()) + list(m.mlp_alpha.parameters()) + list(m.mlp_fuse.parameters())
+                      if p.requires_grad]
+            th.autograd.backward(hats, gr.reshape(hats.shape), inputs=[h_all, feat] + params)
+        # the endpoint rows of the reverse sweep's gradient buffer, as TargetGatherFn.backward fills them
+        fast = st.complete and st.active is None
+        st.begin_backward(zero_da=not fast, zero_g=not fast)
+        if fast:
+            ops.target_rows_begin(st.G, tix, st.tflag)
+        ops.scatter_add_targets(st.G, tix, h_all.grad, unique=self.graph.__dict__.get('targets_unique'))
+        self.graph.__dict__['_head_level_th'] = list(self.level_th)
+        self.token = None                       # breaks the batch <-> root-node reference cycle
+        return feat.grad
+
+
+class HeadRootFn(th.autograd.Function):
+    @staticmethod
+    def forward(ctx, sweep_token, feat_map, hb):
+        ctx.hb = hb
+        return sweep_token.new_zeros(1)
+
+    @staticmethod
+    def backward(ctx, gtoken):
+        dfeat = ctx.hb.backward()
+        return gtoken.new_zeros(1), dfeat, None
+
+
+class HeadLevelFn(th.autograd.Function):
+    """Predictions of one level, computed without an autograd graph; backward parks the gradient in the batch."""
+
+    @staticmethod
+    def forward(ctx, token, hb, slot, h_gnn, path_map, level_id_th):
+        m = hb.model
+        k = h_gnn.shape[0]
+        h = th.cat((h_gnn, m._fcn(path_map), hb.alpha_of(slot, level_id_th).expand(k, m.global_dim)), 1)
+        ctx.hb, ctx.slot = hb, slot
+        return m.mlp_fuse(h).squeeze(-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.hb.grads[ctx.slot] = g
+        return g.new_zeros(1), None, None, None, None, None
+
+
 class PathModel(nn.Module):
     """src/model.py:249-292: fusion head. forward() is called once per level (src/train.py:503)."""
 
@@ -145,6 +239,20 @@ class PathModel(nn.Module):
         return self.fcn(path_map)
 
     def forward(self, graph, nodes, eids, target_list, level_id, level_id_th, path_map):
+        if self._lazy_ok(graph, target_list, path_map):
+            h_gnn = self.gnn(graph, nodes, eids, target_list, level_id)        # advances the (speculative) sweep
+            st = graph._sweep
+            if st is not None and st.spec_token is not None and st.need_grad and h_gnn.requires_grad:
+                hb = st.__dict__.get('head_batch')
+                if hb is None or hb.feat_map is not path_map.feat_map or hb.model is not self:
+                    hb = st.__dict__['head_batch'] = _HeadBatch(self, graph, st, path_map.feat_map, path_map.masks)
+                slot = len(hb.grads)
+                hb.tix.append(st.spec_tix[-1])
+                hb.paths.append(path_map.paths)
+                hb.level_th.append(level_id_th)
+                hb.grads.append(None)
+                return HeadLevelFn.apply(hb.token, hb, slot, h_gnn.detach(), path_map, level_id_th)
+            return self._fuse_level(h_gnn, self._fcn(path_map), target_list, level_id_th)
         if self.fcn is not None and len(target_list) != 0:
             h_cnn = self._fcn(path_map)
         else:
@@ -153,6 +261,9 @@ class PathModel(nn.Module):
         h_gnn = self.gnn(graph, nodes, eids, target_list, level_id) if self.gnn is not None else None
         if len(target_list) == 0:
             return None
+        return self._fuse_level(h_gnn, h_cnn, target_list, level_id_th)
+
+    def _fuse_level(self, h_gnn, h_cnn, target_list, level_id_th):
         h_global = self.mlp_alpha(level_id_th).expand(len(target_list), 32)
         if h_cnn is None:
             h = th.cat([h_gnn, h_global], dim=1)
@@ -161,6 +272,11 @@ class PathModel(nn.Module):
         else:
             h = th.cat((h_gnn, h_cnn, h_global), 1)
         return self.mlp_fuse(h).squeeze(-1)
+
+    def _lazy_ok(self, graph, target_list, path_map):
+        """The deferred head needs: training (grad mode), all three branches, a lazy path map, and targets."""
+        return (LAZY_HEAD and th.is_grad_enabled() and self.gnn is not None and isinstance(self.fcn, nn.Linear)
+                and isinstance(path_map, MaskedPathMap) and len(target_list) != 0 and path_map.feat_map.requires_grad)
 
     def forward_sweep(self, graph, level_nodes, targets, target_levels, path_map):
         """Whole-sweep entry: every level of one mini-batch in a single call.
