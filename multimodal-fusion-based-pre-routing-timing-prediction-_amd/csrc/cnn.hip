@@ -4,6 +4,7 @@
 // Replaces the torch modules inside the reference's src/Unet.py:8-119 and LayoutNet (src/model.py:216-247).
 #include "gemm_engine.h"
 #include "conv_direct.h"
+#include "conv_tile.h"
 #include "conv_wgrad_narrow.h"
 
 namespace mmft {
@@ -26,8 +27,10 @@ __global__ void __launch_bounds__(256) dgrad_weight_kernel(const float* __restri
 
 static int conv_fwd_launch(const float* x, const float* w, const float* bias, float* y, int Nimg, int H, int W, int Ci,
                            int Co, int KH, int KW, int pad, int act, float slope, hipStream_t st) {
-  if (conv_direct_ok(x, w, bias, y, W, Ci, Co, KH, KW, pad))
+  if (conv_direct_ok(x, w, bias, y, W, Ci, Co, KH, KW, pad)) {
+    if (conv_tile_ok(H, W)) return conv_tile_launch(x, w, bias, y, Nimg, H, W, Ci, Co, act, slope, st);
     return conv_direct_launch(x, w, bias, y, Nimg, H, W, Ci, Co, act, slope, st);
+  }
   int M = Nimg * H * W, N = Co, K = KH * KW * Ci;
   DenseMK wl{w, nullptr, K, N, (K % 4 == 0) && aligned16(w)};
   Epi epi{y, Co, nullptr, bias, nullptr, nullptr, 0, EPI_STORE, act, slope, 0, (Co % 4 == 0) && aligned16(y)};
@@ -562,8 +565,10 @@ int mmft_conv2d_dgrad(const float* dy, const float* w, float* dx, int Nimg, int 
   MMFT_REQUIRE(workspace && workspace_bytes >= need, "conv2d_dgrad: workspace too small");
   DeviceGuard dg(device);
   hipStream_t st = (hipStream_t)stream;
-  if (conv_direct_ok(dy, w, nullptr, dx, W, Co, Ci, KH, KW, pad))      // narrow layers: the kernel flips w while staging it
+  if (conv_direct_ok(dy, w, nullptr, dx, W, Co, Ci, KH, KW, pad)) {    // narrow layers: the kernel flips w while staging it
+    if (conv_tile_ok(H, W)) return conv_tile_launch(dy, w, nullptr, dx, Nimg, H, W, Co, Ci, ACT_NONE, 0.f, st, 1);
     return conv_direct_launch(dy, w, nullptr, dx, Nimg, H, W, Co, Ci, ACT_NONE, 0.f, st, 1);
+  }
   hipLaunchKernelGGL(dgrad_weight_kernel, dim3(ew_grid(need / 4)), dim3(256), 0, st, w, workspace, Co, KH, KW, Ci);
   int rc = check_launch("dgrad_weight");
   if (rc) return rc;
