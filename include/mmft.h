@@ -438,6 +438,19 @@ long long mmft_minmax_workspace_bytes(int n, int ncol);
 int mmft_minmax_normalize(float* feat, long long ld, int n, int C, int start_col, float* workspace,
                           long long workspace_bytes, int device, void* stream);
 
+/* ---- OutConv of the layout U-Net, fused (src/Unet.py:71-82): 1x1 convolution to one channel + bias, 2x2 pooling
+ * (mode: MMFT_POOL_MAX / MMFT_POOL_AVG), ReLU.  x [N][H][W][Ci] (NHWC), w [Ci], bias [1] or NULL, out / gout [N][H/2][W/2].
+ * Supported: Ci in {16, 32}, H even, W % 32 == 0 (mmft_outconv_supported); other shapes use mmft_conv2d_* + mmft_pool2x2_*
+ * + mmft_act_*.  The backward recomputes the pixel values from x (nothing is saved by the forward), writes every element
+ * of dx, and (accumulate = 0) stores or (1) adds dw [Ci] and db [1] (db may be NULL). */
+int mmft_outconv_supported(int H, int W, int Ci);
+int mmft_outconv_fwd(const float* x, const float* w, const float* bias, float* out, int Nimg, int H, int W, int Ci, int mode,
+                     int device, void* stream);
+long long mmft_outconv_bwd_workspace_bytes(int Nimg, int H, int W, int Ci);
+int mmft_outconv_bwd(const float* x, const float* w, const float* bias, const float* gout, float* dx, float* dw, float* db,
+                     int accumulate, int Nimg, int H, int W, int Ci, int mode, float* workspace, long long workspace_bytes,
+                     int device, void* stream);
+
 /* ---- streams with a share of the compute units -----------------------------------------------------------------------
  * The step's two independent branches (netlist sweep: src/model.py:176-214; layout U-Net: src/Unet.py:85-113) are
  * replayed on two HIP streams.  mmft_stream_create_cu_mask creates a stream whose kernels may only occupy the CUs whose

@@ -107,8 +107,7 @@ class OutConv(nn.Module):
         self.conv = nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size=1), pooling, nn.ReLU(inplace=True))
 
     def forward(self, x):
-        y = C.conv2d(x, self.conv[0].weight, self.conv[0].bias, pad=0)
-        return C.relu(C.pool2x2(y, _pool_mode(self.conv[1])))
+        return C.outconv(x, self.conv[0].weight, self.conv[0].bias, _pool_mode(self.conv[1]))
 
 
 class UNet(nn.Module):

@@ -102,6 +102,40 @@ def pool2x2(x, mode):
     return Pool2x2Fn.apply(x, mode)
 
 
+class OutConvFn(torch.autograd.Function):
+    """relu(pool(conv1x1(x) + b)) of OutConv (src/Unet.py:71-82) as one kernel per direction; the backward recomputes
+    the pixel values from x, so only x is kept."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, mode):
+        xn = ops.to_nhwc(x)
+        ctx.mode, ctx.has_bias = mode, b is not None
+        ctx.sinks = (gradsink.of(w), gradsink.of(b))
+        ctx.save_for_backward(xn, w, b)
+        return ops.outconv_fwd(xn, w, b, mode)
+
+    @staticmethod
+    def backward(ctx, gout):
+        xn, w, b = ctx.saved_tensors
+        g = gout if gout.is_contiguous() else gout.contiguous()
+        res = {}
+
+        def compute(ow, ob):
+            dx, dw, db = ops.outconv_bwd(xn, w, b, g, ctx.mode, dw=ow.reshape(-1) if ow is not None else None,
+                                         db=ob.reshape(-1) if ob is not None else None)
+            res['dx'] = dx
+            return dw.reshape(w.shape), (db.reshape(b.shape) if b is not None else None)
+        dw, db = gradsink.deliver_pair(ctx.sinks[0], ctx.sinks[1] if ctx.has_bias else None, compute)
+        return res['dx'], dw, db, None
+
+
+def outconv(x, w, b, mode):
+    """OutConv body: fused when the shape allows it, else conv2d + pool2x2 + relu."""
+    if w.shape[0] == 1 and ops.is_nhwc(x) and ops.outconv_supported(x, w):
+        return OutConvFn.apply(x, w, b, mode)
+    return relu(pool2x2(conv2d(x, w, b, pad=0), mode))
+
+
 class UpsampleBilinear2xFn(torch.autograd.Function):
     """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)  (src/Unet.py:50)."""
 

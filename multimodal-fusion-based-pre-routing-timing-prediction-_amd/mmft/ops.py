@@ -703,6 +703,43 @@ def bn_train_bwd(gy, x, y, gamma, mean, invstd, relu, dgamma=None, dbeta=None, b
     return dx, dgamma, dbeta
 
 
+def outconv_supported(x, w):
+    """True when the fused OutConv kernels take this layer: [N, Ci, H, W] channels_last input, a [1, Ci, 1, 1] weight."""
+    if w.dim() != 4 or w.shape[0] != 1 or w.shape[2] != 1 or w.shape[3] != 1 or not w.is_contiguous() or w.data_ptr() % 16:
+        return False
+    N, Ci, H, W = x.shape
+    return Ci == w.shape[1] and bool(lib.query('mmft_outconv_supported', H, W, Ci))
+
+
+def outconv_fwd(x, w, bias, mode):
+    """relu(pool2x2(conv1x1(x) + bias)) -> [N, 1, H/2, W/2]  (mmft_outconv_fwd; src/Unet.py:71-82)."""
+    _nhwc(x, 'x'); _chk(w, 'w')
+    N, Ci, H, W = x.shape
+    if bias is not None:
+        _chk(bias, 'bias')
+    out = torch.empty((N, 1, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    dev, st = lib.stream_args(x)
+    lib.call('mmft_outconv_fwd', x, w, bias, out, N, H, W, Ci, mode, dev, st)
+    return out
+
+
+def outconv_bwd(x, w, bias, gout, mode, dw=None, db=None):
+    """(dx, dw, db) of the fused OutConv; dw / db are written into the given tensors when present."""
+    _nhwc(x, 'x'); _chk(w, 'w'); _chk(gout, 'gout')
+    N, Ci, H, W = x.shape
+    if gout.numel() != N * (H // 2) * (W // 2) or not gout.is_contiguous():
+        raise ValueError('outconv_bwd: gout must be a contiguous [N, 1, H/2, W/2] tensor')
+    dx = empty_nhwc(N, Ci, H, W, x.device)
+    dw = torch.empty(Ci, dtype=torch.float32, device=x.device) if dw is None else dw
+    if bias is not None and db is None:
+        db = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = lib.workspace(x.device, lib.query('mmft_outconv_bwd_workspace_bytes', N, H, W, Ci))
+    dev, st = lib.stream_args(x)
+    lib.call('mmft_outconv_bwd', x, w, bias, gout, dx, dw, db if bias is not None else None, 0, N, H, W, Ci, mode, ws,
+             ws.numel() * 4, dev, st)
+    return dx, dw, db
+
+
 def pool2x2_fwd(x, mode):
     _nhwc(x, 'x')
     N, C, H, W = x.shape

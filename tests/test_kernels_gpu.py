@@ -320,3 +320,34 @@ def test_mlp2_rows_fused(dev, n):
     refd = torch.zeros((N, 128), dtype=torch.float64)
     refd[r.cpu()] = (dh @ w1.double()).cpu()
     assert rel_err(DA, refd) < TOL
+
+
+@pytest.mark.parametrize('pooling', ['max', 'avg'])
+@pytest.mark.parametrize('N,H,W,Ci', [(2, 8, 32, 16), (1, 64, 256, 16), (3, 6, 64, 32)])
+def test_outconv_fused_vs_torch(dev, pooling, N, H, W, Ci):
+    """OutConv (src/Unet.py:71-82: 1x1 conv -> pool -> ReLU) as one kernel per direction against torch in fp64:
+    output, input gradient, weight and bias gradients; the unfused composition must agree with it too."""
+    from mmft import cnn as C
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(1, Ci, 1, 1, generator=g) * 0.3
+    b = torch.randn(1, generator=g) * 0.1
+    gy = torch.randn(N, 1, H // 2, W // 2, generator=g)
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+    y = torch.nn.functional.conv2d(xd, wd, bd)
+    y = torch.nn.functional.max_pool2d(y, 2) if pooling == 'max' else torch.nn.functional.avg_pool2d(y, 2)
+    ref = torch.relu(y)
+    ref.backward(gy.double())
+    mode = ops.POOL_MAX if pooling == 'max' else ops.POOL_AVG
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wg, bg = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    assert ops.outconv_supported(xg, wg)
+    out = C.outconv(xg, wg, bg, mode)
+    assert out.shape == ref.shape and rel_err(out, ref) < 1e-5
+    out.backward(gy.to(dev))
+    assert rel_err(xg.grad, xd.grad) < 1e-5
+    assert rel_err(wg.grad, wd.grad) < 1e-5 and rel_err(bg.grad, bd.grad) < 1e-5
+    # the composition the other shapes take
+    x2 = xg.detach().clone().requires_grad_(True)
+    out2 = C.relu(C.pool2x2(C.conv2d(x2, wg, bg, pad=0), mode))
+    assert rel_err(out2, out) < 1e-5
