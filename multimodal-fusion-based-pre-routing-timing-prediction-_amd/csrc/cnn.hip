@@ -31,6 +31,8 @@ static int conv_fwd_launch(const float* x, const float* w, const float* bias, fl
     if (conv_tile_ok(H, W)) return conv_tile_launch(x, w, bias, y, Nimg, H, W, Ci, Co, act, slope, st);
     return conv_direct_launch(x, w, bias, y, Nimg, H, W, Ci, Co, act, slope, st);
   }
+  if (conv_tile_rgb_shape(Ci, Co, KH, KW, pad) && conv_tile_ok(H, W) && aligned16(y) && (!bias || aligned16(bias)))
+    return conv_tile_launch(x, w, bias, y, Nimg, H, W, Ci, Co, act, slope, st);       // the 3-channel first layer
   int M = Nimg * H * W, N = Co, K = KH * KW * Ci;
   DenseMK wl{w, nullptr, K, N, (K % 4 == 0) && aligned16(w)};
   Epi epi{y, Co, nullptr, bias, nullptr, nullptr, 0, EPI_STORE, act, slope, 0, (Co % 4 == 0) && aligned16(y)};

@@ -17,7 +17,9 @@
 
 namespace mmft {
 
-template <int CI, int CO, int TH, int TW>
+// CS: channels of the input tensor in memory.  CS == CI, or CS < 4 with CI == 16 (the RGB input of the first layer,
+// src/Unet.py:93: its pixels are 12 bytes, loaded as scalars; the other 13 channels of the LDS tile stay zero).
+template <int CI, int CO, int TH, int TW, int CS = CI>
 __global__ void __launch_bounds__(256) conv3x3_tile_kernel(ConvDirectArgs a, int tiles) {
   constexpr int XR = TH + 2, XC = TW + 2, PIX = CI + 8, CB = CI / 16, MB = CO / 16;
   constexpr int STEPS = TH * TW / 16, SPR = TW / 16, SPW = STEPS / 4;
@@ -38,7 +40,10 @@ __global__ void __launch_bounds__(256) conv3x3_tile_kernel(ConvDirectArgs a, int
       for (int m = 0; m < MB; ++m) {
         const int co = m * 16 + r, ci = c * 16 + 4 * q;
         f32x4 v;
-        if (!a.flip) {
+        if constexpr (CS != CI) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = ci + j < CS ? a.w[((long long)co * 9 + t) * CS + ci + j] : 0.f;
+        } else if (!a.flip) {
           v = *reinterpret_cast<const f32x4*>(a.w + ((long long)co * 9 + t) * CI + ci);
         } else {
           // dx = conv(dy, w') with w'[co][tap][ci] = w[ci][8 - tap][co]  (w: the layer's forward weight [CI][3][3][CO])
@@ -51,7 +56,11 @@ __global__ void __launch_bounds__(256) conv3x3_tile_kernel(ConvDirectArgs a, int
 #pragma unroll
   for (int m = 0; m < MB; ++m) bias[m] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + m * 16 + 4 * q) : zero;
 
-  constexpr int XG = CI / 4, XI = XR * XC * XG, NX = (XI + 255) / 256;
+  constexpr int XG = CS == CI ? CI / 4 : 1, XI = XR * XC * XG, NX = (XI + 255) / 256;
+  if constexpr (CS != CI) {
+    for (int e = tid; e < XR * XC * PIX / 4; e += 256) reinterpret_cast<s16x4*>(xs)[e] = s16x4{0, 0, 0, 0};
+    __syncthreads();
+  }
   f32x4 xr[NX];
   auto request = [&](int tile) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, img = tile / (tiles_x * tiles_y);
@@ -63,7 +72,14 @@ __global__ void __launch_bounds__(256) conv3x3_tile_kernel(ConvDirectArgs a, int
       const int cg = it % XG, col = (it / XG) % XC, row = it / (XG * XC);
       const int yy = y0 - 1 + row, xx = x0 - 1 + col;
       const bool ok = it < XI && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + ((img0 + (ok ? yy : y0)) * a.W + (ok ? xx : x0)) * CI + cg * 4);
+      const float* src = a.x + ((img0 + (ok ? yy : y0)) * a.W + (ok ? xx : x0)) * CS + cg * 4;
+      f32x4 v = zero;
+      if constexpr (CS == CI) {
+        v = *reinterpret_cast<const f32x4*>(src);
+      } else {
+#pragma unroll
+        for (int j = 0; j < CS; ++j) v[j] = src[j];
+      }
       xr[k] = ok ? v : zero;
     }
   };
@@ -119,6 +135,9 @@ __global__ void __launch_bounds__(256) conv3x3_tile_kernel(ConvDirectArgs a, int
 
 constexpr int CVT_TH = 4, CVT_TW = 64;
 
+// the RGB first layer (forward only: nothing needs the gradient of the images)
+inline bool conv_tile_rgb_shape(int Ci, int Co, int KH, int KW, int pad) { return Ci == 3 && Co == 16 && KH == 3 && KW == 3 && pad == 1; }
+
 inline bool conv_tile_ok(int H, int W) {
   static int off = -1;
   if (off < 0) {
@@ -128,7 +147,7 @@ inline bool conv_tile_ok(int H, int W) {
   return !off && math_mode() == MMFT_MATH_BF16 && H % CVT_TH == 0 && W % CVT_TW == 0;
 }
 
-template <int CI, int CO>
+template <int CI, int CO, int CS = CI>
 inline void conv_tile_launch_t(const ConvDirectArgs& a, hipStream_t st) {
   const int tiles = a.N * (a.H / CVT_TH) * (a.W / CVT_TW);
   static int cap = 0;
@@ -137,16 +156,17 @@ inline void conv_tile_launch_t(const ConvDirectArgs& a, hipStream_t st) {
     cap = e && atoi(e) > 0 ? atoi(e) : 1024;
   }
   const int grid = tiles < cap ? tiles : cap;
-  const double flops = 2.0 * a.N * a.H * a.W * CO * 9.0 * CI;
-  const double bytes = 4.0 * a.N * a.H * a.W * (CI + CO) + 4.0 * CO * 9 * CI;
-  MMFT_LAUNCH("conv3x3_tile_kernel", flops, bytes, (conv3x3_tile_kernel<CI, CO, CVT_TH, CVT_TW>), dim3(grid), dim3(256), st, a,
-              tiles);
+  const double flops = 2.0 * a.N * a.H * a.W * CO * 9.0 * CS;
+  const double bytes = 4.0 * a.N * a.H * a.W * (CS + CO) + 4.0 * CO * 9 * CS;
+  MMFT_LAUNCH("conv3x3_tile_kernel", flops, bytes, (conv3x3_tile_kernel<CI, CO, CVT_TH, CVT_TW, CS>), dim3(grid), dim3(256), st,
+              a, tiles);
 }
 
 inline int conv_tile_launch(const float* x, const float* w, const float* bias, float* y, int Nimg, int H, int W, int Ci,
                             int Co, int act, float slope, hipStream_t st, int flip = 0) {
   ConvDirectArgs a{x, w, bias, y, Nimg, H, W, act, slope, flip};
-  if (Ci == 16 && Co == 16) conv_tile_launch_t<16, 16>(a, st);
+  if (Ci == 3 && Co == 16) conv_tile_launch_t<16, 16, 3>(a, st);
+  else if (Ci == 16 && Co == 16) conv_tile_launch_t<16, 16>(a, st);
   else if (Ci == 16 && Co == 32) conv_tile_launch_t<16, 32>(a, st);
   else if (Ci == 32 && Co == 16) conv_tile_launch_t<32, 16>(a, st);
   else conv_tile_launch_t<32, 32>(a, st);

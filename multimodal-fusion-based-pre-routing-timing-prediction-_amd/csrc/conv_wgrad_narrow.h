@@ -43,7 +43,9 @@ struct ConvWgradCfg {
   static constexpr int LDS_BYTES = XS_BYTES > RED_BYTES ? XS_BYTES : RED_BYTES;
 };
 
-template <int CI, int CO, int TH, int TW>
+// CS: channels of x in memory (CS == CI, or the 3-channel image of the first layer with CI == 16: scalar loads, the
+// other LDS channels stay zero, and only dw[co][tap][0..CS) is written to the slab).
+template <int CI, int CO, int TH, int TW, int CS = CI>
 __global__ void __launch_bounds__(256) conv3x3_wgrad_narrow_kernel(ConvWgradArgs a) {
   using C = ConvWgradCfg<CI, CO, TH, TW>;
   constexpr int XR = C::XR, XC = C::XC, PIX = C::PIX, CB = CI / 16, MB = CO / 16;
@@ -70,7 +72,11 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_narrow_kernel(ConvWgradArgs
 
   // Staging: x item = (halo row, halo column, channel group of 4), one 16-byte load each; dy fragment = (step of this
   // wave, 16-channel block), loaded in the natural layout (lane = pixel r, channels 4q..4q+3 of the block).
-  constexpr int XG = CI / 4, XI = XR * XC * XG, NX = (XI + 255) / 256;
+  constexpr int XG = CS == CI ? CI / 4 : 1, XI = XR * XC * XG, NX = (XI + 255) / 256;
+  if constexpr (CS != CI) {
+    for (int e = tid; e < XR * XC * PIX / 4; e += 256) reinterpret_cast<s16x4*>(xs)[e] = s16x4{0, 0, 0, 0};
+    __syncthreads();
+  }
   f32x4 xr[NX], dr[SPW][MB];
   s16x4 af[SPW][MB];
   auto request = [&](int tile) {
@@ -84,7 +90,14 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_narrow_kernel(ConvWgradArgs
       const int yy = y0 - 1 + row, xx = x0 - 1 + col;
       const bool ok = it < XI && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
       // out-of-image items read the tile's first pixel (always valid) and are zeroed by the select
-      const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + ((img0 + (ok ? yy : y0)) * a.W + (ok ? xx : x0)) * CI + cg * 4);
+      const float* src = a.x + ((img0 + (ok ? yy : y0)) * a.W + (ok ? xx : x0)) * CS + cg * 4;
+      f32x4 v = zero;
+      if constexpr (CS == CI) {
+        v = *reinterpret_cast<const f32x4*>(src);
+      } else {
+#pragma unroll
+        for (int j = 0; j < CS; ++j) v[j] = src[j];
+      }
       xr[k] = ok ? v : zero;
     }
 #pragma unroll
@@ -152,14 +165,19 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_narrow_kernel(ConvWgradArgs
     }
     __syncthreads();
   }
-  float* out = a.slabs + (long long)blockIdx.x * (CO * 9 * CI);
-  for (int e = tid * 4; e < CO * 9 * CI; e += 1024)
-    *reinterpret_cast<f32x4*>(out + e) = *reinterpret_cast<const f32x4*>(red + e);
+  float* out = a.slabs + (long long)blockIdx.x * (CO * 9 * CS);
+  if constexpr (CS == CI) {
+    for (int e = tid * 4; e < CO * 9 * CI; e += 1024)
+      *reinterpret_cast<f32x4*>(out + e) = *reinterpret_cast<const f32x4*>(red + e);
+  } else {
+    for (int e = tid; e < CO * 9 * CS; e += 256) out[e] = red[(e / CS) * CI + e % CS];
+  }
 }
 
 template <int TH>
 inline bool conv_wgrad_narrow_shape_ok(int H, int W, int Ci, int Co, int KH, int KW, int pad) {
-  return KH == 3 && KW == 3 && pad == 1 && (Ci == 16 || Ci == 32) && (Co == 16 || Co == 32) && W % 64 == 0 && H % TH == 0;
+  return KH == 3 && KW == 3 && pad == 1 && (((Ci == 16 || Ci == 32) && (Co == 16 || Co == 32)) || (Ci == 3 && Co == 16)) &&
+         W % 64 == 0 && H % TH == 0;
 }
 
 // 4 x 64 pixel tiles: 19 KB of LDS at Ci = 16, 32 KB at Ci = 32
@@ -190,19 +208,19 @@ inline int conv_wgrad_narrow_grid(int Nimg, int H, int W, int Ci) {
   return (int)g;
 }
 
-template <int CI, int CO>
+template <int CI, int CO, int CS = CI>
 inline void conv_wgrad_narrow_launch_t(const ConvWgradArgs& a, int grid, hipStream_t st) {
   constexpr int TW = wgn_tw(CI);
   using C = ConvWgradCfg<CI, CO, WGN_TH, TW>;
-  const double flops = 2.0 * a.N * a.H * a.W * CO * 9.0 * CI;
-  const double bytes = 4.0 * a.N * a.H * a.W * (CI + CO);
+  const double flops = 2.0 * a.N * a.H * a.W * CO * 9.0 * CS;
+  const double bytes = 4.0 * a.N * a.H * a.W * (CS + CO);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_narrow_kernel<CI, CO, WGN_TH, TW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_narrow_kernel<CI, CO, WGN_TH, TW, CS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     attr_set = true;
   }
-  MMFT_LAUNCH_LDS("conv3x3_wgrad_narrow_kernel", flops, bytes, (conv3x3_wgrad_narrow_kernel<CI, CO, WGN_TH, TW>), dim3(grid),
+  MMFT_LAUNCH_LDS("conv3x3_wgrad_narrow_kernel", flops, bytes, (conv3x3_wgrad_narrow_kernel<CI, CO, WGN_TH, TW, CS>), dim3(grid),
                   dim3(256), C::LDS_BYTES, st, a);
 }
 
@@ -210,7 +228,8 @@ inline void conv_wgrad_narrow_launch_t(const ConvWgradArgs& a, int grid, hipStre
 inline int conv_wgrad_narrow_launch(const float* x, const float* dy, float* slabs, int Nimg, int H, int W, int Ci, int Co,
                                     int grid, hipStream_t st) {
   ConvWgradArgs a{x, dy, slabs, Nimg, H, W, Nimg * (H / WGN_TH) * (W / wgn_tw(Ci))};
-  if (Ci == 16 && Co == 16) conv_wgrad_narrow_launch_t<16, 16>(a, grid, st);
+  if (Ci == 3 && Co == 16) conv_wgrad_narrow_launch_t<16, 16, 3>(a, grid, st);
+  else if (Ci == 16 && Co == 16) conv_wgrad_narrow_launch_t<16, 16>(a, grid, st);
   else if (Ci == 16 && Co == 32) conv_wgrad_narrow_launch_t<16, 32>(a, grid, st);
   else if (Ci == 32 && Co == 16) conv_wgrad_narrow_launch_t<32, 16>(a, grid, st);
   else conv_wgrad_narrow_launch_t<32, 32>(a, grid, st);

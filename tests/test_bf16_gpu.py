@@ -73,7 +73,7 @@ def test_linear_wgrad_with_bias(dev, rows, out, inn, representable):
                                            (2, 8, 8, 16, 1, 1),
                                            # H % 4 == 0, W % 64 == 0, 16 / 32 channels: the tile-resident weight-gradient kernel
                                            (2, 8, 64, 16, 16, 3), (1, 12, 128, 32, 16, 3), (3, 36, 64, 32, 32, 3),
-                                           (1, 128, 256, 16, 16, 3)])
+                                           (1, 128, 256, 16, 16, 3), (2, 16, 64, 3, 16, 3)])
 @pytest.mark.parametrize('representable', [True, False])
 def test_conv_forward_dgrad_wgrad(dev, N, H, W, Ci, Co, k, representable):
     x = rnd(N, Ci, H, W, seed=7, representable=representable)

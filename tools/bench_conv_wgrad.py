@@ -44,12 +44,13 @@ for N, H, W, Ci, Co in shapes:
         ops.conv2d_wgrad(x, g, 3, 3, 1)
     torch.cuda.synchronize()
     L.mmft_prof_enable(0)
-    if os.environ.get('FWD', '1') == '1' and Ci >= 16:
+    if os.environ.get('FWD', '1') == '1' and (Ci >= 16 or Ci == 3):
         w = (torch.randn(Co, Ci, 3, 3, device=dev) * 0.1).contiguous(memory_format=torch.channels_last)
         L.mmft_prof_enable(1)
         for _ in range(5):
             ops.conv2d_fwd(x, w, None, 1)
-            ops.conv2d_dgrad(g, w, 1)
+            if Ci >= 16:
+                ops.conv2d_dgrad(g, w, 1)
         torch.cuda.synchronize()
         L.mmft_prof_enable(0)
     print(f'{N}x{H}x{W} Ci={Ci:3d} Co={Co:3d}: {us:7.1f} us incl. slab reduce   ({mb:6.1f} MB -> {mb / us:.2f} TB/s)   [{kernel_times()}]')
