@@ -47,7 +47,8 @@ static int conv_fwd_launch(const float* x, const float* w, const float* bias, fl
 // ------------------------------------------------------------------ BatchNorm (train mode)
 // stage 1: per (group, row-block) partial sums of (x - shift) and (x - shift)^2, shift = first row of
 // the group (removes the mean offset from the E[x^2]-E[x]^2 cancellation); stage 2 combines in fp64.
-constexpr int BN_ROWS_PER_BLOCK = 512;
+// rows per block = ceil(rows / blocks_per_group); the host picks blocks_per_group so that a layer of any size launches
+// on the order of 2048 workgroups (bn_blocks) - with a fixed 512 rows the 64x64 and 32x32 stages ran on 64 and 16.
 
 // C % 4 == 0: a thread owns one 4-channel group (16-byte loads) and walks the rows of its block with two rows in
 // flight; C % 4 != 0 falls back to one channel per thread.
@@ -57,8 +58,9 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const float* __restrict
   __shared__ float red[2][256 * VEC];
   int grp = blockIdx.x / blocks_per_group, blk = blockIdx.x % blocks_per_group;
   const float* xg = x + (long long)grp * rows * C;
-  long long r0 = (long long)blk * BN_ROWS_PER_BLOCK;
-  long long r1 = r0 + BN_ROWS_PER_BLOCK < rows ? r0 + BN_ROWS_PER_BLOCK : rows;
+  const long long rpb = (rows + blocks_per_group - 1) / blocks_per_group;
+  long long r0 = (long long)blk * rpb;
+  long long r1 = r0 + rpb < rows ? r0 + rpb : rows;
   const int cg = C / VEC;                              // channel groups per row
   int lanes_per_row = cg < 256 ? cg : 256;
   int rstep = 256 / lanes_per_row;
@@ -206,8 +208,9 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float* __rest
   __shared__ float red[2][256 * VEC];
   int grp = blockIdx.x / blocks_per_group, blk = blockIdx.x % blocks_per_group;
   long long base = (long long)grp * rows * C;
-  long long r0 = (long long)blk * BN_ROWS_PER_BLOCK;
-  long long r1 = r0 + BN_ROWS_PER_BLOCK < rows ? r0 + BN_ROWS_PER_BLOCK : rows;
+  const long long rpb = (rows + blocks_per_group - 1) / blocks_per_group;
+  long long r0 = (long long)blk * rpb;
+  long long r1 = r0 + rpb < rows ? r0 + rpb : rows;
   const int cg = C / VEC;
   int lanes_per_row = cg < 256 ? cg : 256;
   int rstep = 256 / lanes_per_row;
@@ -538,7 +541,12 @@ __global__ void __launch_bounds__(256) nchw_nhwc_kernel(const float* __restrict_
   }
 }
 
-static inline int bn_blocks(long long rows) { return cdiv(rows, BN_ROWS_PER_BLOCK); }
+static inline int bn_blocks(int groups, long long rows) {
+  if ((long long)groups * rows < 16384) return cdiv(rows, 512);     // small layers: one or a few blocks per group
+  long long rpb = 64;                                  // at least 64 rows per block, at most 512
+  while (rpb < 512 && (long long)groups * cdiv(rows, rpb) > 2048) rpb *= 2;
+  return cdiv(rows, rpb);
+}
 
 }  // namespace mmft
 
@@ -634,7 +642,7 @@ int mmft_conv2d_wgrad(const float* x, const float* dy, float* dw, int Nimg, int 
 }
 
 long long mmft_bn_workspace_bytes(int groups, long long rows, int C) {
-  return ((long long)groups * bn_blocks(rows) * 2 * C + (long long)groups * 2 * C) * 4;
+  return ((long long)groups * bn_blocks(groups, rows) * 2 * C + (long long)groups * 2 * C) * 4;
 }
 
 int mmft_bn_train_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
@@ -646,7 +654,7 @@ int mmft_bn_train_fwd(const float* x, float* y, const float* gamma, const float*
   MMFT_REQUIRE(workspace && workspace_bytes >= mmft_bn_workspace_bytes(groups, rows, C), "bn_train_fwd: workspace too small");
   DeviceGuard dg(device);
   hipStream_t st = (hipStream_t)stream;
-  int bpg = bn_blocks(rows);
+  int bpg = bn_blocks(groups, rows);
   ProfScope ps("bn_train_fwd(3 kernels)", 0.0, 3.0 * 4.0 * groups * rows * C, st);
   const bool v4 = (C % 4 == 0) && aligned16(x) && aligned16(y);
   if (v4) hipLaunchKernelGGL(bn_partial_kernel<4>, dim3(groups * bpg), dim3(256), 0, st, x, rows, C, bpg, workspace);
@@ -675,7 +683,7 @@ int mmft_bn_train_bwd(const float* gy, const float* x, const float* y, const flo
   MMFT_REQUIRE(workspace && workspace_bytes >= mmft_bn_workspace_bytes(groups, rows, C), "bn_train_bwd: workspace too small");
   DeviceGuard dg(device);
   hipStream_t st = (hipStream_t)stream;
-  int bpg = bn_blocks(rows);
+  int bpg = bn_blocks(groups, rows);
   float* coef = workspace + (long long)groups * bpg * 2 * C;
   ProfScope ps("bn_train_bwd(3 kernels)", 0.0, (beta ? 5.0 : 7.0) * 4.0 * groups * rows * C, st);
   const bool v4 = (C % 4 == 0) && aligned16(x) && aligned16(gy) && aligned16(dx) && (!y || aligned16(y));

