@@ -180,7 +180,7 @@ def _cos(a, b):
 
 def test_config_a_step_vs_oracle_bf16(dev):
     """One full config-A train step (U-Net, 32-level sweep, fusion head, MSE, backward) in bf16 mode against the fp64
-    oracle: predictions within 5e-2 of their scale, loss within 10 %, gradient directions within cos >= 0.98 (GNN, fusion head) / >= 0.90 (U-Net, mean >= 0.97)."""
+    oracle: predictions within 5e-2 of their scale, loss within 10 %, gradient directions within cos >= 0.98 (GNN, fusion head) / >= 0.85 (U-Net, mean >= 0.97)."""
     from mmft.synth import config_design
     from mmft.train import build_models, TrainStep
     from mmft.fusion import mse_loss
