@@ -300,19 +300,23 @@ def main():
                 r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] else 0, r['bytes'] / (r['ms'] * 1e-3) / 1e9 if r['ms'] else 0))
         top = rows[0]
         per_launch_ms = top['ms'] / top['launches']
-        if top['flops'] > 0:
-            ach = top['flops'] / (top['ms'] * 1e-3) / 1e12
-            peak = PEAK_MFMA_BF16_TFLOPS if (args.dtype == 'bf16' and 'bf16' in top['name']) else PEAK_MFMA_F32_TFLOPS
-            roofline = dict(bound='mfma', achieved=ach, peak=peak, unit='TFLOP/s', frac=ach / peak, traffic=None)
-            # a bf16 contraction fed from fp32 tensors is bound by its operand bytes long before the matrix pipe:
-            # report the HBM view of the same launch beside it
+        peak_tf = PEAK_MFMA_BF16_TFLOPS if (args.dtype == 'bf16' and 'bf16' in top['name']) else PEAK_MFMA_F32_TFLOPS
+        tfs = top['flops'] / (top['ms'] * 1e-3) / 1e12
+        gbs = top['bytes'] / (top['ms'] * 1e-3) / 1e9
+        # which roof bounds the launch: its arithmetic intensity (algorithmic flops per algorithmic byte) against the ridge
+        # of the two peaks.  A bf16 contraction fed from fp32 tensors sits far below the bf16 ridge (312 flop/B): HBM-bound.
+        ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+        intensity = top['flops'] / top['bytes'] if top['bytes'] > 0 else float('inf')
+        if top['flops'] > 0 and intensity >= ridge:
+            roofline = dict(bound='mfma', achieved=tfs, peak=peak_tf, unit='TFLOP/s', frac=tfs / peak_tf, traffic=None)
             if top['bytes'] > 0:
-                gbs = top['bytes'] / (top['ms'] * 1e-3) / 1e9
                 roofline['hbm_view'] = dict(achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS)
         else:
-            ach = top['bytes'] / (top['ms'] * 1e-3) / 1e9
-            roofline = dict(bound='hbm', achieved=ach, peak=PEAK_HBM_GBS, unit='GB/s', frac=ach / PEAK_HBM_GBS,
-                            traffic=None)
+            roofline = dict(bound='hbm', achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS, traffic=None)
+            if top['flops'] > 0:
+                roofline['mfma_view'] = dict(achieved=tfs, peak=peak_tf, unit='TFLOP/s', frac=tfs / peak_tf)
+        roofline['flop_per_byte'] = None if intensity == float('inf') else intensity
+        roofline['ridge_flop_per_byte'] = ridge
         roofline['traffic'], roofline['traffic_source'] = pmc_traffic(top['name'])
         roofline.update(kernel=top['name'], launches_per_step=top['launches'] / nprof,
                         avg_launch_us=per_launch_ms * 1e3, share_of_device_time=top['ms'] / total_ms,
