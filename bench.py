@@ -168,6 +168,15 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def limit_host_threads(world=1):
+    """The GPU box shows 256 CPUs but grants a 16-CPU quota (cgroup cpu.max): a single OpenMP region of torch's CPU
+    side (index packing, link lists) spun up on 256 threads exhausts a 100 ms quota period in a few ms and the whole
+    process is then throttled for the rest of it - 50-70 ms stalls in the middle of a step (measured: cpu.stat
+    nr_throttled).  Keep the host side to the threads it is entitled to."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(16, n) // max(1, world)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -203,6 +212,7 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    limit_host_threads(1)            # per rank: the 8-GPU node grants each rank its own share
     if world != args.gpus:
         log(f'WORLD_SIZE={world} differs from --gpus {args.gpus}: running (and reporting) {world} ranks')
     rank = int(os.environ.get('RANK', '0'))

@@ -9,6 +9,7 @@ from mmft import lib
 from mmft.synth import synth_design
 from mmft.train import build_models, TrainStep
 
+torch.set_num_threads(int(os.environ.get('THREADS', '16')))     # see bench.limit_host_threads
 dev = torch.device('cuda:0')
 lib.set_math_mode(os.environ.get('MMFT_MATH', 'bf16'))
 designs = [synth_design(N=65536, L=64, tile=256, seed=1000 + i) for i in range(8)]
