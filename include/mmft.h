@@ -128,6 +128,19 @@ int mmft_level_fwd_bf16(float* h, const float* pre, long long ld, int D, const i
                         const void* w2_bf16, const float* b2, float* hid_out, long long ldhid, int relu,
                         const unsigned char* active, const int* in_cell_driver, long long alg_bytes, int device,
                         void* stream);
+/* MMFT_MATH_BF16: the feature MLPs fc_cell_self / fc_net_self (Linear(fin, 256)-ReLU-Linear(256, 128) over the contiguous node
+ * rows row0 .. row0 + n - 1; src/model.py:48-51,66-67,148-153,186-189) WITHOUT a stored hidden tensor.
+ *   fwd: out[row] = (relu)(W2 relu(W1 x[row] + b1) + b2); x [.][ldx >= fin] and out [.][ldout] are indexed by NODE id.
+ *   bwd: from g [.][ldg] (gradient of the output rows) and x: dw1 [256][fin], db1 [256], dw2 [128][256], db2 [128], stored
+ *        (accumulate = 0) or added (1); the hidden activations are recomputed with the forward's instruction sequence.
+ * fin <= 64; w1 [256][fin], w2 [128][256] plain fp32 row-major (rounded to bf16 in the kernel). */
+int mmft_mlp2_feat_fwd_bf16(const float* x, long long ldx, int row0, int n, int fin, const float* w1, const float* b1,
+                            const float* w2, const float* b2, float* out, long long ldout, int relu_out, int device,
+                            void* stream);
+long long mmft_mlp2_feat_bwd_workspace_bytes(int n, int fin);
+int mmft_mlp2_feat_bwd_bf16(const float* g, long long ldg, const float* x, long long ldx, int row0, int n, int fin,
+                            const float* w1, const float* b1, const float* w2, float* dw1, float* db1, float* dw2, float* db2,
+                            int accumulate, float* workspace, long long workspace_bytes, int device, void* stream);
 /* out[c] (+)= sum_r g[idx[r]][c]   (bias gradients); workspace >= mmft_colsum_workspace_bytes */
 long long mmft_colsum_workspace_bytes(int rows, int cols);
 int mmft_colsum(const float* g, const int* idx, long long ld, int rows, int cols, float* out, int accumulate,

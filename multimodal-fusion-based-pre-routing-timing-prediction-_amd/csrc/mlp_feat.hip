@@ -1,0 +1,376 @@
+// The feature MLPs of the sweep, fc_cell_self / fc_net_self (Linear(fin, 256) - ReLU - Linear(256, 128) over ALL cell /
+// net nodes, src/model.py:48-51,66-67,148-153,186-189), bf16 math mode, WITHOUT storing the hidden activations.
+//
+// As two GEMMs per MLP the hidden tensor H (rows x 256 fp32 = 268 MB per MLP at config B) was written once and read three
+// times per step (second forward GEMM, weight gradient of layer 2, fused first-layer gradients): 4 x 111 us forward,
+// 2 x (120 + 103) us backward, all of it HBM time.  fin is 36 / 2: recomputing H costs 1-5 % of the MLP's flops, so
+//   * forward  (mmft_mlp2_feat_fwd_bf16): one kernel per MLP reads X, keeps the 64 x 256 hidden tile in LDS as bf16 and
+//     writes only the output rows;
+//   * backward (mmft_mlp2_feat_bwd_bf16): one kernel per MLP reads G (gradient of the output rows) and X, recomputes
+//     H = relu(X W1^T + b1) with the forward's instruction sequence (bitwise the forward's H, so the ReLU mask agrees),
+//     forms dH = (G W2) * (H > 0) in registers and accumulates all four gradients
+//         dW2 += G^T H,  db2 += sum G,  dW1 += dH^T X,  db1 += sum dH
+//     in MFMA accumulators across the 32-row tiles of a persistent workgroup (the contractions over rows take their
+//     operands from transposed bf16 copies of the tile in LDS); one slab per workgroup, summed in a fixed order.
+// Lane layouts are those of mlp2_bf16.hip: A = weights / transposed tiles (lane = output feature, 8 consecutive k),
+// B = row tiles (lane = row or feature, 8 consecutive k), D[m][n] at lane (n = lane & 15, q = lane >> 4) = rows 4q..4q+3.
+#include "gemm_bf16.h"
+
+namespace mmft {
+
+constexpr int MF_HD = 256, MF_D2 = 128;
+
+__device__ __forceinline__ unsigned short mf_bf16(float v) { return (unsigned short)(pack_bf16(v, 0.f) & 0xffff); }
+
+__device__ __forceinline__ bf16x8 mf_pack8(const float* v) {
+  u32x4 p = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+  return __builtin_bit_cast(bf16x8, p);
+}
+
+// A fragment of W1 [HD][fin] for hidden column `col`, k = k0 .. k0 + 7 (zero beyond fin)
+__device__ __forceinline__ bf16x8 mf_w1_frag(const float* __restrict__ w1, int fin, int col, int k0) {
+  float v[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) v[t] = k0 + t < fin ? w1[(long long)col * fin + k0 + t] : 0.f;
+  return mf_pack8(v);
+}
+
+struct FeatFwdArgs {
+  const float* x;
+  long long ldx;
+  int row0, n, fin;
+  const float *w1, *b1, *w2, *b2;
+  float* out;
+  long long ldout;
+  int relu_out;
+};
+
+template <int KS>   // K steps of 32 for the first layer (fin <= 32 KS)
+__global__ void __launch_bounds__(512) mlp2_feat_fwd_kernel(FeatFwdArgs a) {
+  constexpr int BM = 64, RT = BM / 16, XS = KS * 32 + 8, HS = MF_HD + 8;
+  __shared__ __attribute__((aligned(16))) unsigned short xs[BM * XS];
+  __shared__ __attribute__((aligned(16))) unsigned short hs[BM * HS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.x * BM;
+  bf16x8 w1f[2][KS], w2f[8];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) w1f[j][ks] = mf_w1_frag(a.w1, a.fin, wave * 32 + j * 16 + r16, ks * 32 + q * 8);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) w2f[ks] = mf_pack8(a.w2 + (long long)(wave * 16 + r16) * MF_HD + ks * 32 + q * 8);
+  for (int e = tid; e < BM * KS * 32; e += 512) {
+    const int r = e / (KS * 32), k = e % (KS * 32);
+    const float v = (m0 + r < a.n && k < a.fin) ? a.x[(long long)(a.row0 + m0 + r) * a.ldx + k] : 0.f;
+    xs[r * XS + k] = mf_bf16(v);
+  }
+  __syncthreads();
+  f32x4 acc1[RT][2];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xs + (i * 16 + r16) * XS + ks * 32 + q * 8);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[j][ks], xf, acc1[i][j], 0, 0, 0);
+    }
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = i * 16 + r16, nn = wave * 32 + j * 16 + q * 4;
+      f32x4 v = acc1[i][j] + *reinterpret_cast<const f32x4*>(a.b1 + nn);
+      v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+      v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+      const unsigned lo = pack_bf16(v.x, v.y), hi = pack_bf16(v.z, v.w);
+      *reinterpret_cast<unsigned long long*>(hs + m * HS + nn) = ((unsigned long long)hi << 32) | lo;
+    }
+  __syncthreads();
+  f32x4 acc2[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hs + (i * 16 + r16) * HS + ks * 32 + q * 8);
+      acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[ks], hf, acc2[i], 0, 0, 0);
+    }
+  const int nn = wave * 16 + q * 4;
+  const f32x4 b2v = *reinterpret_cast<const f32x4*>(a.b2 + nn);
+#pragma unroll
+  for (int i = 0; i < RT; ++i) {
+    const int m = m0 + i * 16 + r16;
+    if (m >= a.n) continue;
+    f32x4 v = acc2[i] + b2v;
+    if (a.relu_out) {
+      v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+      v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(a.out + (long long)(a.row0 + m) * a.ldout + nn) = v;
+  }
+}
+
+struct FeatBwdArgs {
+  const float* g;
+  long long ldg;
+  const float* x;
+  long long ldx;
+  int row0, n, fin;
+  const float *w1, *b1, *w2;
+  float* slabs;        // [gridDim.x][slab]: dw1 [HD][fin] | db1 [HD] | dw2 [D2][HD] | db2 [D2]
+  long long slab;
+};
+
+template <int KS>
+__global__ void __launch_bounds__(512) mlp2_feat_bwd_kernel(FeatBwdArgs a) {
+  constexpr int BM = 32, KP = KS * 32, XS = KP + 8, GS = MF_D2 + 8, TS = BM + 8, KB = KP / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];       // 70 KB: above the static limit
+  unsigned short* xs = lds;                       // X tile, natural    [row][k]
+  unsigned short* gs = xs + BM * XS;              // G tile, natural    [row][d2]
+  unsigned short* xT = gs + BM * GS;              // X tile, transposed [k][row]
+  unsigned short* gT = xT + KP * TS;              // G tile, transposed [d2][row]
+  unsigned short* hT = gT + MF_D2 * TS;           // H tile, transposed [col][row]
+  unsigned short* dT = hT + MF_HD * TS;           // dH tile, transposed [col][row]
+  f32x4(*gred)[32] = reinterpret_cast<f32x4(*)[32]>(hT);      // end of the kernel only (16 x 32 x 16 B <= hT)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+  // weights in registers for the life of the workgroup
+  bf16x8 w1f[2][KS], w2tf[2][4];
+  f32x4 b1v[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = wave * 32 + j * 16 + r16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) w1f[j][ks] = mf_w1_frag(a.w1, a.fin, col, ks * 32 + q * 8);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {         // A fragment of W2^T: W2T[col][d2] = w2[d2][col], d2 = 32 ks + 8 q ..
+      float v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = a.w2[(long long)(ks * 32 + q * 8 + t) * MF_HD + col];
+      w2tf[j][ks] = mf_pack8(v);
+    }
+    b1v[j] = *reinterpret_cast<const f32x4*>(a.b1 + wave * 32 + j * 16 + q * 4);
+  }
+  f32x4 dw2[2][8], dw1[2][KB], dsum[2], gsum = zero;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    dsum[j] = zero;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) dw2[j][d] = zero;
+#pragma unroll
+    for (int k = 0; k < KB; ++k) dw1[j][k] = zero;
+  }
+
+  const int ntiles = (a.n + BM - 1) / BM;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * BM;
+    // ---- stage G (natural + transposed) and X (natural + transposed); rows past the end are zero
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int e = tid + it * 512, r = e >> 5, c = (e & 31) * 4;          // (row, 4 consecutive d2): c is the same for both
+      f32x4 v = zero;
+      if (m0 + r < a.n) v = *reinterpret_cast<const f32x4*>(a.g + (long long)(a.row0 + m0 + r) * a.ldg + c);
+      gsum += v;
+      const unsigned lo = pack_bf16(v.x, v.y), hi = pack_bf16(v.z, v.w);
+      *reinterpret_cast<unsigned long long*>(gs + r * GS + c) = ((unsigned long long)hi << 32) | lo;
+      gT[(c + 0) * TS + r] = (unsigned short)(lo & 0xffff);
+      gT[(c + 1) * TS + r] = (unsigned short)(lo >> 16);
+      gT[(c + 2) * TS + r] = (unsigned short)(hi & 0xffff);
+      gT[(c + 3) * TS + r] = (unsigned short)(hi >> 16);
+    }
+    for (int e = tid; e < BM * KP; e += 512) {
+      const int r = e / KP, k = e % KP;
+      const float v = (m0 + r < a.n && k < a.fin) ? a.x[(long long)(a.row0 + m0 + r) * a.ldx + k] : 0.f;
+      const unsigned short b = mf_bf16(v);
+      xs[r * XS + k] = b;
+      xT[k * TS + r] = b;
+    }
+    __syncthreads();
+    // ---- H = relu(X W1^T + b1), dH = (G W2) * (H > 0): hidden columns [32 wave, 32 wave + 32) of the 32 rows
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f32x4 acc1[2] = {zero, zero}, acc3[2] = {zero, zero};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xs + (i * 16 + r16) * XS + ks * 32 + q * 8);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[j][ks], xf, acc1[j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 gf = *reinterpret_cast<const bf16x8*>(gs + (i * 16 + r16) * GS + ks * 32 + q * 8);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc3[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2tf[j][ks], gf, acc3[j], 0, 0, 0);
+      }
+      const int m = i * 16 + r16;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int nn = wave * 32 + j * 16 + q * 4;
+        f32x4 hv = acc1[j] + b1v[j], dh = acc3[j];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          hv[t] = hv[t] > 0.f ? hv[t] : 0.f;
+          dh[t] = hv[t] > 0.f ? dh[t] : 0.f;
+        }
+        dsum[j] += dh;
+        const unsigned hl = pack_bf16(hv.x, hv.y), hh = pack_bf16(hv.z, hv.w);
+        const unsigned dl = pack_bf16(dh.x, dh.y), dhh = pack_bf16(dh.z, dh.w);
+        hT[(nn + 0) * TS + m] = (unsigned short)(hl & 0xffff); hT[(nn + 1) * TS + m] = (unsigned short)(hl >> 16);
+        hT[(nn + 2) * TS + m] = (unsigned short)(hh & 0xffff); hT[(nn + 3) * TS + m] = (unsigned short)(hh >> 16);
+        dT[(nn + 0) * TS + m] = (unsigned short)(dl & 0xffff); dT[(nn + 1) * TS + m] = (unsigned short)(dl >> 16);
+        dT[(nn + 2) * TS + m] = (unsigned short)(dhh & 0xffff); dT[(nn + 3) * TS + m] = (unsigned short)(dhh >> 16);
+      }
+    }
+    __syncthreads();
+    // ---- contractions over the tile's 32 rows (one K step): dW2^T[col][d2] += H^T G, dW1^T... [col][k] += dH^T X
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = wave * 32 + j * 16 + r16;
+      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hT + col * TS + q * 8);
+      const bf16x8 df = *reinterpret_cast<const bf16x8*>(dT + col * TS + q * 8);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const bf16x8 gf = *reinterpret_cast<const bf16x8*>(gT + (d * 16 + r16) * TS + q * 8);
+        dw2[j][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf, gf, dw2[j][d], 0, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < KB; ++k) {
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xT + (k * 16 + r16) * TS + q * 8);
+        dw1[j][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, xf, dw1[j][k], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- the workgroup's slab
+  float* sl = a.slabs + (long long)blockIdx.x * a.slab;
+  float* s_dw1 = sl;
+  float* s_db1 = s_dw1 + (long long)MF_HD * a.fin;
+  float* s_dw2 = s_db1 + MF_HD;
+  float* s_db2 = s_dw2 + (long long)MF_D2 * MF_HD;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int colq = wave * 32 + j * 16 + q * 4;           // D[m = col][n]: lane (n = r16, q) holds cols colq .. colq + 3
+#pragma unroll
+    for (int d = 0; d < 8; ++d) *reinterpret_cast<f32x4*>(s_dw2 + (long long)(d * 16 + r16) * MF_HD + colq) = dw2[j][d];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int kk = k * 16 + r16;
+      if (kk < a.fin) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s_dw1[(long long)(colq + t) * a.fin + kk] = dw1[j][k][t];
+      }
+    }
+    // db1: sum over the 16 row lanes (rows live on r16), fixed butterfly order
+    f32x4 v = dsum[j];
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] += __shfl_xor(v[t], o, 64);
+    }
+    if (r16 == 0) *reinterpret_cast<f32x4*>(s_db1 + colq) = v;
+  }
+  // db2: thread t summed d2 group (t & 31) over its rows; 16 threads share a group
+  __syncthreads();
+  gred[tid >> 5][tid & 31] = gsum;
+  __syncthreads();
+  if (tid < 32) {
+    f32x4 v = gred[0][tid];
+    for (int p = 1; p < 16; ++p) v += gred[p][tid];
+    *reinterpret_cast<f32x4*>(s_db2 + tid * 4) = v;
+  }
+}
+
+// out[e] (+)= sum over slabs (fixed order); the four gradients are the four segments of a slab
+__global__ void __launch_bounds__(256) mlp2_feat_reduce_kernel(const float* __restrict__ slabs, int nslab, long long slab, int fin,
+                                                               float* __restrict__ dw1, float* __restrict__ db1,
+                                                               float* __restrict__ dw2, float* __restrict__ db2, int accumulate) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= slab) return;
+  float s = 0.f;
+  for (int b = 0; b < nslab; ++b) s += slabs[(long long)b * slab + e];
+  const long long n1 = (long long)MF_HD * fin, n2 = n1 + MF_HD, n3 = n2 + (long long)MF_D2 * MF_HD;
+  float* dst = e < n1 ? dw1 + e : e < n2 ? db1 + (e - n1) : e < n3 ? dw2 + (e - n2) : db2 + (e - n3);
+  *dst = accumulate ? *dst + s : s;
+}
+
+template <int KS>
+constexpr int feat_bwd_lds() {
+  constexpr int BM = 32, KP = KS * 32, XS = KP + 8, GS = MF_D2 + 8, TS = BM + 8;
+  return (BM * XS + BM * GS + KP * TS + MF_D2 * TS + 2 * MF_HD * TS) * 2;
+}
+
+static inline long long feat_slab(int fin) { return (long long)MF_HD * fin + MF_HD + (long long)MF_D2 * MF_HD + MF_D2; }
+static inline int feat_bwd_grid(int n) {
+  int tiles = cdiv(n, 32);
+  return tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256;
+}
+
+}  // namespace mmft
+
+using namespace mmft;
+
+extern "C" int mmft_mlp2_feat_fwd_bf16(const float* x, long long ldx, int row0, int n, int fin, const float* w1, const float* b1,
+                                       const float* w2, const float* b2, float* out, long long ldout, int relu_out, int device,
+                                       void* stream) {
+  MMFT_REQUIRE(x && w1 && b1 && w2 && b2 && out, "mlp2_feat_fwd_bf16: null pointer");
+  MMFT_REQUIRE(n >= 0 && row0 >= 0 && fin >= 1 && fin <= 64 && ldx >= fin, "mlp2_feat_fwd_bf16: bad sizes (fin <= 64)");
+  MMFT_REQUIRE(ldout % 4 == 0 && aligned16(out) && aligned16(w2) && aligned16(b1) && aligned16(b2),
+               "mlp2_feat_fwd_bf16: out / w2 / biases must be 16-byte aligned");
+  if (n == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  FeatFwdArgs a{x, ldx, row0, n, fin, w1, b1, w2, b2, out, ldout, relu_out};
+  const double fl = 2.0 * n * ((double)fin * MF_HD + (double)MF_HD * MF_D2), by = 4.0 * n * ((double)fin + MF_D2);
+  if (fin <= 32)
+    MMFT_LAUNCH("mlp2_feat_fwd_kernel", fl, by, mlp2_feat_fwd_kernel<1>, dim3(cdiv(n, 64)), dim3(512), (hipStream_t)stream, a);
+  else
+    MMFT_LAUNCH("mlp2_feat_fwd_kernel", fl, by, mlp2_feat_fwd_kernel<2>, dim3(cdiv(n, 64)), dim3(512), (hipStream_t)stream, a);
+  return check_launch("mlp2_feat_fwd_bf16");
+}
+
+extern "C" long long mmft_mlp2_feat_bwd_workspace_bytes(int n, int fin) {
+  if (n <= 0 || fin < 1 || fin > 64) return 0;
+  return (long long)feat_bwd_grid(n) * feat_slab(fin) * 4;
+}
+
+extern "C" int mmft_mlp2_feat_bwd_bf16(const float* g, long long ldg, const float* x, long long ldx, int row0, int n, int fin,
+                                       const float* w1, const float* b1, const float* w2, float* dw1, float* db1, float* dw2,
+                                       float* db2, int accumulate, float* workspace, long long workspace_bytes, int device,
+                                       void* stream) {
+  MMFT_REQUIRE(g && x && w1 && b1 && w2 && dw1 && db1 && dw2 && db2, "mlp2_feat_bwd_bf16: null pointer");
+  MMFT_REQUIRE(n > 0 && row0 >= 0 && fin >= 1 && fin <= 64 && ldx >= fin && ldg >= MF_D2, "mlp2_feat_bwd_bf16: bad sizes (fin <= 64)");
+  MMFT_REQUIRE(ldg % 4 == 0 && aligned16(g) && aligned16(b1), "mlp2_feat_bwd_bf16: g / b1 must be 16-byte aligned");
+  MMFT_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= mmft_mlp2_feat_bwd_workspace_bytes(n, fin),
+               "mlp2_feat_bwd_bf16: workspace too small");
+  DeviceGuard dg(device);
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = feat_bwd_grid(n);
+  const long long slab = feat_slab(fin);
+  FeatBwdArgs a{g, ldg, x, ldx, row0, n, fin, w1, b1, w2, workspace, slab};
+  const double fl = 2.0 * n * (2.0 * fin * MF_HD + 2.0 * MF_HD * MF_D2), by = 4.0 * n * ((double)fin + MF_D2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp2_feat_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              feat_bwd_lds<1>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp2_feat_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              feat_bwd_lds<2>());
+    attr_set = true;
+  }
+  if (fin <= 32)
+    MMFT_LAUNCH_LDS("mlp2_feat_bwd_kernel", fl, by, mlp2_feat_bwd_kernel<1>, dim3(grid), dim3(512), feat_bwd_lds<1>(), st, a);
+  else
+    MMFT_LAUNCH_LDS("mlp2_feat_bwd_kernel", fl, by, mlp2_feat_bwd_kernel<2>, dim3(grid), dim3(512), feat_bwd_lds<2>(), st, a);
+  int rc = check_launch("mlp2_feat_bwd_bf16");
+  if (rc) return rc;
+  hipLaunchKernelGGL(mlp2_feat_reduce_kernel, dim3(cdiv(slab, 256)), dim3(256), 0, st, workspace, grid, slab, fin, dw1, db1, dw2,
+                     db2, accumulate ? 1 : 0);
+  return check_launch("mlp2_feat_reduce");
+}

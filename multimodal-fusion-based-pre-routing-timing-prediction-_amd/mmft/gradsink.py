@@ -136,6 +136,28 @@ def deliver_pair(sink_a, sink_b, compute):
     return res[0], res[1]
 
 
+def deliver_many(sinks, compute):
+    """deliver_pair for any number of gradients produced by ONE kernel: compute(*outs) -> tuple in memory order."""
+    outs, late, fresh_sinks = [], [], []
+    for sink in sinks:
+        mem = _memory_order(sink[0])[0] if sink is not None else None
+        if mem is not None and sink[1] != _epoch[0]:
+            fresh_sinks.append(sink)
+            outs.append(mem); late.append(None)
+        else:
+            outs.append(None); late.append(mem)
+    res = list(compute(*outs))
+    for sink in fresh_sinks:                 # marked after the producing kernel has been issued
+        _mark(sink)
+    for i in range(len(sinks)):
+        if outs[i] is not None:
+            res[i] = None
+        elif late[i] is not None:
+            late[i].add_(res[i].reshape(late[i].shape))
+            res[i] = None
+    return res
+
+
 def fresh(sink):
     """True when nothing has been written into the sink during the current step."""
     return sink[1] != _epoch[0]

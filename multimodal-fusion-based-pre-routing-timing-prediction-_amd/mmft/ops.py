@@ -253,6 +253,54 @@ def level_fwd_bf16(h, pre, in_net, in_cell, net_range, cell_rows, A, LSE, w1p, b
              _edge_drivers(in_cell_driver, in_cell[1]), int(alg_bytes), dev, st)
 
 
+def mlp2_feat_fusable(fin, HD, D2):
+    return 1 <= fin <= 64 and HD == 256 and D2 == 128
+
+
+def mlp2_feat_fwd_bf16(x, rows, w1, b1, w2, b2, out, relu_out=False):
+    """out[rows] = (relu)(w2 relu(w1 x[rows] + b1) + b2) over a contiguous node range rows = (row0, n), no hidden tensor
+    stored (mmft_mlp2_feat_fwd_bf16; bf16 math mode)."""
+    _rows2d(x, 'x'); _rows2d(out, 'out')
+    for t, nm in ((w1, 'w1'), (b1, 'b1'), (w2, 'w2'), (b2, 'b2')):
+        _chk(t, nm)
+        if not t.is_contiguous():
+            raise ValueError(f'mlp2_feat_fwd_bf16: {nm} must be contiguous')
+    fin = x.shape[1]
+    if tuple(w1.shape) != (256, fin) or tuple(w2.shape) != (128, 256) or out.shape[1] != 128 or out.shape[0] != x.shape[0]:
+        raise ValueError('mlp2_feat_fwd_bf16: fin -> 256 -> 128 over node-indexed buffers')
+    rt, row0, n = _rowspec(rows, x.shape[0], 'rows')
+    if rt is not None:
+        raise ValueError('mlp2_feat_fwd_bf16: rows must be a (row0, n) range')
+    dev, st = lib.stream_args(x)
+    lib.call('mmft_mlp2_feat_fwd_bf16', x, x.stride(0), row0, n, fin, w1, b1, w2, b2, out, out.stride(0), int(relu_out), dev, st)
+    return out
+
+
+def mlp2_feat_bwd_bf16(g, x, rows, w1, b1, w2, dw1=None, db1=None, dw2=None, db2=None):
+    """(dw1, db1, dw2, db2) of that MLP from the gradient g of its output rows; the hidden activations are recomputed
+    (mmft_mlp2_feat_bwd_bf16)."""
+    _rows2d(g, 'g'); _rows2d(x, 'x')
+    fin = x.shape[1]
+    rt, row0, n = _rowspec(rows, x.shape[0], 'rows')
+    if rt is not None or g.shape[0] != x.shape[0] or g.shape[1] != 128:
+        raise ValueError('mlp2_feat_bwd_bf16: rows must be a (row0, n) range over node-indexed g [N, 128] / x [N, fin]')
+    mk = lambda t, shape: torch.empty(shape, dtype=torch.float32, device=x.device) if t is None else t
+    dw1, db1, dw2, db2 = mk(dw1, (256, fin)), mk(db1, (256,)), mk(dw2, (128, 256)), mk(db2, (128,))
+    for t, nm in ((dw1, 'dw1'), (db1, 'db1'), (dw2, 'dw2'), (db2, 'db2'), (w1, 'w1'), (b1, 'b1'), (w2, 'w2')):
+        _chk(t, nm)
+        if not t.is_contiguous():
+            raise ValueError(f'mlp2_feat_bwd_bf16: {nm} must be contiguous')
+    if n == 0:
+        for t in (dw1, db1, dw2, db2):
+            t.zero_()
+        return dw1, db1, dw2, db2
+    ws = lib.workspace(x.device, lib.query('mmft_mlp2_feat_bwd_workspace_bytes', n, fin))
+    dev, st = lib.stream_args(x)
+    lib.call('mmft_mlp2_feat_bwd_bf16', g, g.stride(0), x, x.stride(0), row0, n, fin, w1, b1, w2, dw1, db1, dw2, db2, 0, ws,
+             ws.numel() * 4, dev, st)
+    return dw1, db1, dw2, db2
+
+
 def _edge_drivers(drv, indices):
     if drv is None:
         return None

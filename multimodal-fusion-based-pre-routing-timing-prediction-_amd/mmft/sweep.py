@@ -327,8 +327,14 @@ def _batched_param_grads(st, P, dhn_ready=False):
     rn = _cat_rows(st, lambda l: l % 2 == 1)
     rc2 = _cat_rows(st, lambda l: l % 2 == 0 and l > 0)
     zeros = lambda ps: [torch.zeros_like(p) for p in ps]
-    gc = _mlp_grads(st, S[0:4], st.G, rc, st.HS, st.cell_feat, rc, w2c) if rc is not None else zeros(P[0:4])
-    gn = _mlp_grads(st, S[4:8], st.G, rn, st.HS, st.net_feat, rn, w2n) if rn is not None else zeros(P[4:8])
+    if getattr(st, 'feat_fused', False):
+        feat = lambda sinks, rows, X, w1, b1, w2: gradsink.deliver_many(
+            sinks, lambda o1, ob1, o2, ob2: ops.mlp2_feat_bwd_bf16(st.G, X, rows, w1, b1, w2, dw1=o1, db1=ob1, dw2=o2, db2=ob2))
+        gc = feat(S[0:4], rc, st.cell_feat, w1c, b1c, w2c) if rc is not None else zeros(P[0:4])
+        gn = feat(S[4:8], rn, st.net_feat, w1n, b1n, w2n) if rn is not None else zeros(P[4:8])
+    else:
+        gc = _mlp_grads(st, S[0:4], st.G, rc, st.HS, st.cell_feat, rc, w2c) if rc is not None else zeros(P[0:4])
+        gn = _mlp_grads(st, S[4:8], st.G, rn, st.HS, st.net_feat, rn, w2n) if rn is not None else zeros(P[4:8])
     gg = _mlp_grads(st, S[8:12], st.G, rc2, st.HN, st.A, rc2, w2g,
                     st.DHN if (dhn_ready and st.DHN is not None) else None) if rc2 is not None else zeros(P[8:12])
     return gc + gn + gg
@@ -443,6 +449,7 @@ def level_forward(conv, graph, cur_nodes, targets, level_id):
 # costs more than the ~2 us hardware kernel boundary it replaces.  Off by default.
 PERSISTENT_FORWARD = False
 EDGE_DRIVERS = True                 # folded gather: per-edge driver table (3-deep load chain, four edges in flight)
+FEAT_MLP_NO_HIDDEN = True           # bf16 mode: fc_cell_self / fc_net_self as one kernel each way, hidden activations recomputed
 FUSE_LEVEL_FWD = True               # bf16 mode: folded gather + fused MLP of a level pair in one launch (mmft_level_fwd_bf16)
 FOLD_LEVELS = True                  # folded forward chain (one gather per (net, cell) level PAIR) when the graph allows it
 FUSED_FIRST_LAYER_GRADS = True      # mmft_mlp2_first_layer_grads for the *_self MLPs (False: dgrad GEMM + wgrad GEMM)
@@ -490,19 +497,34 @@ class SweepFn(torch.autograd.Function):
         rc2 = _cat_rows(st, lambda l: l % 2 == 0 and l > 0)
         rn = _cat_rows(st, lambda l: l % 2 == 1)
         st.row_sets = (_cat_rows(st, lambda l: l % 2 == 0), rn, rc2)
-        if r0.numel():                                                                   # level 0, :148-153
-            r0s = _cat_rows(st, lambda l: l == 0)
-            _linear_rows(st.cell_feat, w1c, b1c, st.HS, r0s, act=ops.ACT_RELU)
-            _linear_rows(st.HS, w2c, b2c, st.h, r0s, act=act)
+        r0s = _cat_rows(st, lambda l: l == 0) if r0.numel() else None
+        # bf16 mode: the feature MLPs run as one kernel each and their hidden activations (268 MB per MLP at config B)
+        # are never stored - the backward recomputes them (mmft_mlp2_feat_*); needs contiguous row ranges
+        st.feat_fused = (FEAT_MLP_NO_HIDDEN and st.wpack is not None and all(isinstance(r, tuple) for r in (r0s, rc2, rn) if r is not None)
+                         and isinstance(st.row_sets[0], tuple) and ops.mlp2_feat_fusable(st.cell_feat.shape[1], st.Hd, st.D)
+                         and ops.mlp2_feat_fusable(st.net_feat.shape[1], st.Hd, st.D)
+                         and all(p.is_contiguous() for p in P[:8]))
+        if r0s is not None:                                                              # level 0, :148-153
+            if st.feat_fused:
+                ops.mlp2_feat_fwd_bf16(st.cell_feat, r0s, w1c, b1c, w2c, b2c, st.h, relu_out=st.relu)
+            else:
+                _linear_rows(st.cell_feat, w1c, b1c, st.HS, r0s, act=ops.ACT_RELU)
+                _linear_rows(st.HS, w2c, b2c, st.h, r0s, act=act)
         if rc2 is not None:                                                              # fc_cell_self, all cell nodes
-            _linear_rows(st.cell_feat, w1c, b1c, st.HS, rc2, act=ops.ACT_RELU)
-            _linear_rows(st.HS, w2c, b2c, st.h, rc2)
+            if st.feat_fused:
+                ops.mlp2_feat_fwd_bf16(st.cell_feat, rc2, w1c, b1c, w2c, b2c, st.h)
+            else:
+                _linear_rows(st.cell_feat, w1c, b1c, st.HS, rc2, act=ops.ACT_RELU)
+                _linear_rows(st.HS, w2c, b2c, st.h, rc2)
         fold = st.fold if (FOLD_LEVELS and not PERSISTENT_FORWARD and st.attn is None) else None
         if fold is not None:
             st.PRE = st._buf('PRE', st.D)     # fc_net_self outputs live apart from h: the folded gather updates h in place
         if rn is not None:                                                               # fc_net_self, all net nodes
-            _linear_rows(st.net_feat, w1n, b1n, st.HS, rn, act=ops.ACT_RELU)
-            _linear_rows(st.HS, w2n, b2n, st.PRE if fold is not None else st.h, rn)
+            if st.feat_fused:
+                ops.mlp2_feat_fwd_bf16(st.net_feat, rn, w1n, b1n, w2n, b2n, st.PRE if fold is not None else st.h)
+            else:
+                _linear_rows(st.net_feat, w1n, b1n, st.HS, rn, act=ops.ACT_RELU)
+                _linear_rows(st.HS, w2n, b2n, st.PRE if fold is not None else st.h, rn)
         in_net, in_cell = g.csr('in', 'net'), g.csr('in', 'cell')
         persistent = PERSISTENT_FORWARD and ops.mlp2_fusable(st.D, st.Hd, st.D) and len(level_rows) > 1 and st.attn is None
         if persistent:

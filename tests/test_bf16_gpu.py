@@ -273,3 +273,41 @@ def test_fused_level_kernel_equals_two_kernel_form(dev):
         assert torch.equal(x, y)
     for k in res[1][4]:
         assert torch.equal(res[0][4][k], res[1][4][k]), k
+
+
+@pytest.mark.parametrize('fin,n,row0', [(36, 1000, 7), (2, 4099, 0), (36, 70000, 128), (5, 33, 3)])
+@pytest.mark.parametrize('representable', [True, False])
+def test_feature_mlp_without_hidden_tensor(dev, fin, n, row0, representable):
+    """mmft_mlp2_feat_fwd_bf16 / _bwd_bf16 (fc_cell_self / fc_net_self with the hidden activations recomputed instead of
+    stored) against fp64 math that rounds where the kernels round: operands, the hidden tile and the hidden gradient go
+    through bf16, everything accumulates in fp32."""
+    N = row0 + n + 5
+    x = rnd(N, fin, seed=1, representable=representable)
+    w1 = rnd(256, fin, seed=2, representable=representable) * 0.25
+    b1 = rnd(256, seed=3, representable=representable) * 0.25
+    w2 = rnd(128, 256, seed=4, representable=representable) * 0.125
+    b2 = rnd(128, seed=5, representable=representable)
+    g = rnd(N, 128, seed=6, representable=representable)
+    if representable:
+        w1, b1, w2 = bf(w1), bf(b1), bf(w2)
+    sl = slice(row0, row0 + n)
+    xb, w1b, w2b, gb = bf(x).double(), bf(w1).double(), bf(w2).double(), bf(g).double()
+    pre = xb[sl] @ w1b.T + b1.double()
+    H = bf(torch.relu(pre).float()).double()                      # the hidden tile is stored as bf16 in LDS
+    ref = H @ w2b.T + b2.double()
+    out = torch.full((N, 128), 7.0, device=dev)
+    ops.mlp2_feat_fwd_bf16(x.to(dev), (row0, n), w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), out)
+    # the kernels round the hidden tile / hidden gradient to bf16 from an fp32 accumulation, this reference from the exact
+    # value: among 10^7 hidden values a few land on the other side of a rounding boundary (one bf16 ulp = 2^-8 relative
+    # each), so even with representable operands the bar is 1e-3 of the result's scale - a wrong fragment layout is O(1)
+    tol = 1e-3 if representable else TOL
+    assert rel_err(out[sl], ref) < tol
+    assert float((out[:row0] - 7.0).abs().max()) == 0.0 if row0 else True          # rows outside the range are not touched
+    assert float((out[row0 + n:] - 7.0).abs().max()) == 0.0
+    dH = bf(((gb[sl] @ w2b) * (pre > 0)).float()).double()        # ... and so is the hidden gradient
+    dw1, db1, dw2, db2 = ops.mlp2_feat_bwd_bf16(g.to(dev), x.to(dev), (row0, n), w1.to(dev), b1.to(dev), w2.to(dev))
+    scale = tol
+    assert rel_err(dw2, gb[sl].T @ H) < scale
+    assert rel_err(db2, g[sl].double().sum(0)) < 1e-5             # from the fp32 staging registers: exact in both cases
+    assert rel_err(dw1, dH.T @ xb[sl]) < scale
+    assert rel_err(db1, ((gb[sl] @ w2b) * (pre > 0)).sum(0)) < scale
