@@ -52,7 +52,6 @@ __global__ void __launch_bounds__(512) mlp2_feat_fwd_kernel(FeatFwdArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned short hs[BM * HS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.x * BM;
   bf16x8 w1f[2][KS], w2f[8];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
@@ -60,59 +59,82 @@ __global__ void __launch_bounds__(512) mlp2_feat_fwd_kernel(FeatFwdArgs a) {
     for (int ks = 0; ks < KS; ++ks) w1f[j][ks] = mf_w1_frag(a.w1, a.fin, wave * 32 + j * 16 + r16, ks * 32 + q * 8);
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) w2f[ks] = mf_pack8(a.w2 + (long long)(wave * 16 + r16) * MF_HD + ks * 32 + q * 8);
-  for (int e = tid; e < BM * KS * 32; e += 512) {
-    const int r = e / (KS * 32), k = e % (KS * 32);
-    const float v = (m0 + r < a.n && k < a.fin) ? a.x[(long long)(a.row0 + m0 + r) * a.ldx + k] : 0.f;
-    xs[r * XS + k] = mf_bf16(v);
-  }
-  __syncthreads();
-  f32x4 acc1[RT][2];
+  const int nn2 = wave * 16 + q * 4;
+  const f32x4 b2v = *reinterpret_cast<const f32x4*>(a.b2 + nn2);
+  f32x4 b1v[2];
 #pragma unroll
-  for (int i = 0; i < RT; ++i)
+  for (int j = 0; j < 2; ++j) b1v[j] = *reinterpret_cast<const f32x4*>(a.b1 + wave * 32 + j * 16 + q * 4);
+  // The weights (164 KB of fp32) are fetched ONCE per workgroup: the grid is a few workgroups per CU and each walks
+  // tiles of 64 rows; the X elements of tile t + 1 are requested before tile t is multiplied.
+  constexpr int NXE = BM * KS * 32 / 512;
+  float xr[NXE];
+  auto request = [&](int tile) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < NXE; ++k) {
+      const int e = tid + k * 512, r = e / (KS * 32), kk = e % (KS * 32);
+      const int m = tile * BM + r;
+      xr[k] = (m < a.n && kk < a.fin) ? a.x[(long long)(a.row0 + m) * a.ldx + kk] : 0.f;
+    }
+  };
+  const int ntiles = (a.n + BM - 1) / BM;
+  if ((int)blockIdx.x < ntiles) request(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * BM;
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
+    for (int k = 0; k < NXE; ++k) {
+      const int e = tid + k * 512;
+      xs[(e / (KS * 32)) * XS + e % (KS * 32)] = mf_bf16(xr[k]);
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) request(tile + gridDim.x);
+    f32x4 acc1[RT][2];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xs + (i * 16 + r16) * XS + ks * 32 + q * 8);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[j][ks], xf, acc1[i][j], 0, 0, 0);
+      }
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int m = i * 16 + r16, nn = wave * 32 + j * 16 + q * 4;
+        f32x4 v = acc1[i][j] + b1v[j];
+        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+        v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        const unsigned lo = pack_bf16(v.x, v.y), hi = pack_bf16(v.z, v.w);
+        *reinterpret_cast<unsigned long long*>(hs + m * HS + nn) = ((unsigned long long)hi << 32) | lo;
+      }
+    __syncthreads();
+    f32x4 acc2[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hs + (i * 16 + r16) * HS + ks * 32 + q * 8);
+        acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[ks], hf, acc2[i], 0, 0, 0);
+      }
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
-      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xs + (i * 16 + r16) * XS + ks * 32 + q * 8);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[j][ks], xf, acc1[i][j], 0, 0, 0);
+      const int m = m0 + i * 16 + r16;
+      if (m >= a.n) continue;
+      f32x4 v = acc2[i] + b2v;
+      if (a.relu_out) {
+        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+        v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(a.out + (long long)(a.row0 + m) * a.ldout + nn2) = v;
     }
-#pragma unroll
-  for (int i = 0; i < RT; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int m = i * 16 + r16, nn = wave * 32 + j * 16 + q * 4;
-      f32x4 v = acc1[i][j] + *reinterpret_cast<const f32x4*>(a.b1 + nn);
-      v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
-      v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-      const unsigned lo = pack_bf16(v.x, v.y), hi = pack_bf16(v.z, v.w);
-      *reinterpret_cast<unsigned long long*>(hs + m * HS + nn) = ((unsigned long long)hi << 32) | lo;
-    }
-  __syncthreads();
-  f32x4 acc2[RT];
-#pragma unroll
-  for (int i = 0; i < RT; ++i) acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-    for (int i = 0; i < RT; ++i) {
-      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hs + (i * 16 + r16) * HS + ks * 32 + q * 8);
-      acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[ks], hf, acc2[i], 0, 0, 0);
-    }
-  const int nn = wave * 16 + q * 4;
-  const f32x4 b2v = *reinterpret_cast<const f32x4*>(a.b2 + nn);
-#pragma unroll
-  for (int i = 0; i < RT; ++i) {
-    const int m = m0 + i * 16 + r16;
-    if (m >= a.n) continue;
-    f32x4 v = acc2[i] + b2v;
-    if (a.relu_out) {
-      v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
-      v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-    }
-    *reinterpret_cast<f32x4*>(a.out + (long long)(a.row0 + m) * a.ldout + nn) = v;
+    // the next deposit overwrites xs (last read before the barrier above) and the next epilogue hs (last read here)
+    __syncthreads();
   }
 }
 
@@ -170,14 +192,30 @@ __global__ void __launch_bounds__(512) mlp2_feat_bwd_kernel(FeatBwdArgs a) {
   }
 
   const int ntiles = (a.n + BM - 1) / BM;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // G (two 16-byte groups per thread) and X (BM * KP / 512 scalars) of tile t + 1 are requested before tile t is multiplied
+  constexpr int NXE = BM * KP / 512;
+  f32x4 gr[2];
+  float xr[NXE];
+  auto request = [&](int tile) {
     const int m0 = tile * BM;
-    // ---- stage G (natural + transposed) and X (natural + transposed); rows past the end are zero
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int e = tid + it * 512, r = e >> 5, c = (e & 31) * 4;
+      gr[it] = m0 + r < a.n ? *reinterpret_cast<const f32x4*>(a.g + (long long)(a.row0 + m0 + r) * a.ldg + c) : zero;
+    }
+#pragma unroll
+    for (int k = 0; k < NXE; ++k) {
+      const int e = tid + k * 512, r = e / KP, kk = e % KP;
+      xr[k] = (m0 + r < a.n && kk < a.fin) ? a.x[(long long)(a.row0 + m0 + r) * a.ldx + kk] : 0.f;
+    }
+  };
+  if ((int)blockIdx.x < ntiles) request(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // ---- deposit G (natural + transposed) and X (natural + transposed); rows past the end are zero
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int e = tid + it * 512, r = e >> 5, c = (e & 31) * 4;          // (row, 4 consecutive d2): c is the same for both
-      f32x4 v = zero;
-      if (m0 + r < a.n) v = *reinterpret_cast<const f32x4*>(a.g + (long long)(a.row0 + m0 + r) * a.ldg + c);
+      const f32x4 v = gr[it];
       gsum += v;
       const unsigned lo = pack_bf16(v.x, v.y), hi = pack_bf16(v.z, v.w);
       *reinterpret_cast<unsigned long long*>(gs + r * GS + c) = ((unsigned long long)hi << 32) | lo;
@@ -186,13 +224,15 @@ __global__ void __launch_bounds__(512) mlp2_feat_bwd_kernel(FeatBwdArgs a) {
       gT[(c + 2) * TS + r] = (unsigned short)(hi & 0xffff);
       gT[(c + 3) * TS + r] = (unsigned short)(hi >> 16);
     }
-    for (int e = tid; e < BM * KP; e += 512) {
-      const int r = e / KP, k = e % KP;
-      const float v = (m0 + r < a.n && k < a.fin) ? a.x[(long long)(a.row0 + m0 + r) * a.ldx + k] : 0.f;
-      const unsigned short b = mf_bf16(v);
-      xs[r * XS + k] = b;
-      xT[k * TS + r] = b;
+#pragma unroll
+    for (int k = 0; k < NXE; ++k) {
+      const int e = tid + k * 512, r = e / KP, kk = e % KP;
+      const unsigned short b = mf_bf16(xr[k]);
+      xs[r * XS + kk] = b;
+      xT[kk * TS + r] = b;
     }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) request(tile + gridDim.x);
     __syncthreads();
     // ---- H = relu(X W1^T + b1), dH = (G W2) * (H > 0): hidden columns [32 wave, 32 wave + 32) of the 32 rows
 #pragma unroll
@@ -329,10 +369,12 @@ extern "C" int mmft_mlp2_feat_fwd_bf16(const float* x, long long ldx, int row0, 
   DeviceGuard dg(device);
   FeatFwdArgs a{x, ldx, row0, n, fin, w1, b1, w2, b2, out, ldout, relu_out};
   const double fl = 2.0 * n * ((double)fin * MF_HD + (double)MF_HD * MF_D2), by = 4.0 * n * ((double)fin + MF_D2);
+  int grid = cdiv(n, 64);
+  if (grid > 768) grid = 768;                      // three workgroups per CU (43 KB of LDS each)
   if (fin <= 32)
-    MMFT_LAUNCH("mlp2_feat_fwd_kernel", fl, by, mlp2_feat_fwd_kernel<1>, dim3(cdiv(n, 64)), dim3(512), (hipStream_t)stream, a);
+    MMFT_LAUNCH("mlp2_feat_fwd_kernel", fl, by, mlp2_feat_fwd_kernel<1>, dim3(grid), dim3(512), (hipStream_t)stream, a);
   else
-    MMFT_LAUNCH("mlp2_feat_fwd_kernel", fl, by, mlp2_feat_fwd_kernel<2>, dim3(cdiv(n, 64)), dim3(512), (hipStream_t)stream, a);
+    MMFT_LAUNCH("mlp2_feat_fwd_kernel", fl, by, mlp2_feat_fwd_kernel<2>, dim3(grid), dim3(512), (hipStream_t)stream, a);
   return check_launch("mlp2_feat_fwd_bf16");
 }
 
