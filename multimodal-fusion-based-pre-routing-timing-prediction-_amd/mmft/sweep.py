@@ -551,7 +551,10 @@ class SweepFn(torch.autograd.Function):
                     # bf16 mode: gather + fc_cell_neigh of the pair in ONE launch
                     ops.level_fwd_bf16(st.h, st.PRE, in_net, in_cell, fold[net_l]['range'] or (0, 0), crow, st.A, st.LSE,
                                        st.wpack[0], b1g, st.wpack[1], b2g, st.HN, relu=st.relu, active=st.active, in_cell_driver=drv,
-                                       alg_bytes=(meta_n['bytes_mean'] if meta_n else 0) + (meta_c['bytes_softmax'] if meta_c else 0))
+                                       # gather bytes of the pair + what the MLP part must move per cell row: h read and
+                                       # written (2 x 4 D) and the hidden row kept for the reverse sweep (4 Hd)
+                                       alg_bytes=(meta_n['bytes_mean'] if meta_n else 0) + (meta_c['bytes_softmax'] if meta_c else 0)
+                                       + (level_rows[level_id].numel() * (8 * st.D + 4 * st.Hd) if meta_c else 0))
                     continue
                 ops.pair_fwd_gather(st.h, st.PRE, in_net, in_cell, fold[net_l]['range'] or (0, 0), crow, st.A, st.LSE,
                                     relu=st.relu, heavy=fold[level_id]['heavy_in'] if has_cell else None, active=st.active,
