@@ -11,7 +11,10 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 POOL_MAX, POOL_AVG = 0, 1
 # rows with more edges than this get a whole workgroup in the level kernels (graph.hip): a cell row's in-edges (forward
 # gather) / a node's out-edges (reverse pull) are a serial chain of dependent loads in one thread group otherwise
-PAIR_HEAVY_IN, PAIR_HEAVY_OUT = 16, 16
+import os as _os
+# rows with more in- / out-edges than this get a whole workgroup (MMFT_HEAVY_IN / MMFT_HEAVY_OUT override, read at import)
+PAIR_HEAVY_IN = int(_os.environ.get('MMFT_HEAVY_IN', '16'))
+PAIR_HEAVY_OUT = int(_os.environ.get('MMFT_HEAVY_OUT', '16'))
 
 
 def _chk(t, name, dtype=torch.float32):

@@ -392,6 +392,10 @@ def level_forward(conv, graph, cur_nodes, targets, level_id):
             return st.h.new_zeros((0, st.D))
         if st.need_grad:
             st.spec_tix.append(tix)
+            if graph.__dict__.get('_head_takes_gradients'):
+                # the caller (PathModel's deferred head) scatters the endpoint gradients itself from its root node: a
+                # plain gather, no autograd node per level
+                return ops.gather_rows(st.h, tix)
             return TargetGatherFn.apply(st.spec_token, st, tix, graph.__dict__.get('targets_unique'))
         return ops.gather_rows(st.h, tix)
     if level_id == 0 or graph._sweep is None:

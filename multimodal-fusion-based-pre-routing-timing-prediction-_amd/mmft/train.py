@@ -247,7 +247,9 @@ class TrainStep:
             targets = ends_d[pos:pos + k]
             path_map = None
             if k and feat is not None:
-                path_map = MaskedPathMap(b.masks, paths_d[pos:pos + k], feat)      # per-level rows: links on the host
+                # per-level rows; the per-row feature-map offsets come from the packed selection (no lookup launch per
+                # level), the link lists are derived only if a per-level backward asks for them
+                path_map = MaskedPathMap(b.masks, paths_d[pos:pos + k], feat, foff_d[pos:pos + k] if b.B > 1 else None)
             cur = self.pmodel(g, b.level_nodes[level_id], None, targets, level_id, b.level_th[level_id], path_map)
             pos += k
             if cur is not None:

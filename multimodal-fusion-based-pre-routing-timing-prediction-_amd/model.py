@@ -240,9 +240,13 @@ class PathModel(nn.Module):
 
     def forward(self, graph, nodes, eids, target_list, level_id, level_id_th, path_map):
         if self._lazy_ok(graph, target_list, path_map):
-            h_gnn = self.gnn(graph, nodes, eids, target_list, level_id)        # advances the (speculative) sweep
+            graph.__dict__['_head_takes_gradients'] = True                     # speculative sweep: plain gather of h[targets]
+            try:
+                h_gnn = self.gnn(graph, nodes, eids, target_list, level_id)    # advances the (speculative) sweep
+            finally:
+                graph.__dict__['_head_takes_gradients'] = False
             st = graph._sweep
-            if st is not None and st.spec_token is not None and st.need_grad and h_gnn.requires_grad:
+            if st is not None and st.spec_token is not None and st.need_grad and not h_gnn.requires_grad:
                 hb = st.__dict__.get('head_batch')
                 if hb is None or hb.feat_map is not path_map.feat_map or hb.model is not self:
                     hb = st.__dict__['head_batch'] = _HeadBatch(self, graph, st, path_map.feat_map, path_map.masks)
