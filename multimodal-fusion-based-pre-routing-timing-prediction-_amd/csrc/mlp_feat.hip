@@ -18,6 +18,8 @@
 
 namespace mmft {
 
+int launch_slab_reduce(const float* slabs, int splits, long long elems, float* out, int accumulate, hipStream_t st);
+
 constexpr int MF_HD = 256, MF_D2 = 128;
 
 __device__ __forceinline__ unsigned short mf_bf16(float v) { return (unsigned short)(pack_bf16(v, 0.f) & 0xffff); }
@@ -412,6 +414,11 @@ extern "C" int mmft_mlp2_feat_bwd_bf16(const float* g, long long ldg, const floa
     MMFT_LAUNCH_LDS("mlp2_feat_bwd_kernel", fl, by, mlp2_feat_bwd_kernel<2>, dim3(grid), dim3(512), feat_bwd_lds<2>(), st, a);
   int rc = check_launch("mlp2_feat_bwd_bf16");
   if (rc) return rc;
+  // The four gradients are the four segments of a slab.  In FlatAdam's gradient buffer they are neighbours in exactly that
+  // order (weight, bias, weight, bias of one MLP), so ONE parallel slab reduction finishes all of them; scattered outputs take
+  // the segment-aware kernel (one thread per element, 62 us at 256 slabs against 9).
+  if (db1 == dw1 + (long long)MF_HD * fin && dw2 == db1 + MF_HD && db2 == dw2 + (long long)MF_D2 * MF_HD && aligned16(dw1))
+    return launch_slab_reduce(workspace, grid, slab, dw1, accumulate, st);
   hipLaunchKernelGGL(mlp2_feat_reduce_kernel, dim3(cdiv(slab, 256)), dim3(256), 0, st, workspace, grid, slab, fin, dw1, db1, dw2,
                      db2, accumulate ? 1 : 0);
   return check_launch("mlp2_feat_reduce");
