@@ -184,3 +184,28 @@ def test_design_record_roundtrip_and_reference_tuple_converter(tmp_path):
               'path2level', 'path2endpoint', 'arrival_time', 'label'):
         assert np.array_equal(getattr(c, k), getattr(d, k)), k
     assert all(np.array_equal(a, b) for a, b in zip(c.levels, d.levels))
+
+
+def test_bench_pmc_table_lookup(tmp_path, monkeypatch):
+    """bench.pmc_traffic: the committed counter table is only used when its stamp matches the kernel sources of this tree;
+    kernels the launch profiler names without template arguments find their single instantiation."""
+    import json
+    import bench
+    fp = bench.csrc_fingerprint()
+    table = {'__stamp__': {'csrc_sha256': fp},
+             'void mmft::level_fwd_bf16_kernel<16>(mmft::LevelFwdArgs)': {'launches': 3, 'hbm_bytes_per_launch': 46.0e6},
+             'void mmft::gemm_bf16_kernel<mmft::TileCfg<128, 128, 64, 2, 2>, mmft::DenseKM, mmft::DenseKM>(int)': {
+                 'launches': 2, 'hbm_bytes_per_launch': 300.0e6},
+             'void mmft::conv3x3_tile_kernel<16, 16, 4, 64, 16>(mmft::ConvDirectArgs, int)': {'launches': 1, 'hbm_bytes_per_launch': 81.0e6},
+             'void mmft::conv3x3_tile_kernel<32, 16, 4, 64, 32>(mmft::ConvDirectArgs, int)': {'launches': 1, 'hbm_bytes_per_launch': 120.0e6}}
+    path = tmp_path / 'pmc.json'
+    path.write_text(json.dumps(table))
+    monkeypatch.setattr(bench, 'PMC_TABLE', str(path))
+    assert bench.pmc_traffic('level_fwd_bf16_kernel')[0] == 46.0e6                       # one instantiation of that name
+    assert bench.pmc_traffic('gemm_bf16_kernel<TileCfg<128,128,64,2,2>,DenseKM,DenseKM>')[0] == 300.0e6
+    assert bench.pmc_traffic('conv3x3_tile_kernel')[0] is None                           # ambiguous: two instantiations
+    assert bench.pmc_traffic('no_such_kernel')[0] is None
+    table['__stamp__']['csrc_sha256'] = '0' * 64                                         # taken on other sources: never reported
+    path.write_text(json.dumps(table))
+    val, why = bench.pmc_traffic('level_fwd_bf16_kernel')
+    assert val is None and 'stamp' in why
