@@ -110,15 +110,33 @@ def pmc_traffic(kernel):
 
 def prof_report():
     from mmft import lib
-    L = lib.load()
-    need = L.mmft_prof_report(None, 0)
-    buf = ctypes.create_string_buffer(need + 16)
-    L.mmft_prof_report(ctypes.cast(buf, ctypes.c_void_p), need + 16)
-    rows = []
-    for line in buf.value.decode().splitlines():
-        name, n, ms, fl, by = line.split('\t')
-        rows.append(dict(name=name, launches=int(n), ms=float(ms), flops=float(fl), bytes=float(by)))
-    return rows
+    return lib.prof_report()
+
+
+SEC8D_FWD = ('level_fwd_bf16_kernel', 'level_fwd_slots_kernel', 'pair_fwd_gather_kernel', 'seg_mean_fwd_kernel',
+             'seg_softmax_sum_fwd_kernel', 'seg_attn_fwd_kernel')
+SEC8D_BWD = ('level_bwd_pull_kernel', 'level_bwd_pull_attn_kernel')
+
+
+def sec8d_aggregation(designs, rows, nprof, D=128, s=4):
+    """aggregation bytes per design-step, forward `s D (E + N_d) + 4 E + 4 (N_d + L)`, backward
+    `s D (3 E + 2 N_d) + 4 E` (E = net + cell edges, N_d = nodes of level >= 1, s = bytes per stored element), summed
+    over this rank's designs and divided by the device time of ALL launches of the kernels that carry that traffic."""
+    fwd = bwd = 0.0
+    for d in designs:
+        E = int(d.net_src.shape[0]) + int(d.cell_src.shape[0])
+        Nd = int(d.N) - int(len(d.levels[0]))
+        fwd += s * D * (E + Nd) + 4 * E + 4 * (Nd + d.L)
+        bwd += s * D * (3 * E + 2 * Nd) + 4 * E
+    out = {}
+    for key, names, nbytes in (('fwd', SEC8D_FWD, fwd), ('bwd', SEC8D_BWD, bwd)):
+        sel = [r for r in rows if r['name'].split('<')[0] in names]
+        ms = sum(r['ms'] for r in sel) / nprof
+        n = sum(r['launches'] for r in sel) / nprof
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out[key] = dict(bytes_per_step=nbytes, launches_per_step=n, device_ms_per_step=ms, kernels=sorted({r['name'] for r in sel}),
+                        bytes_per_launch=nbytes / n if n else None, achieved_gbs=gbs, frac_of_hbm_peak=gbs / PEAK_HBM_GBS)
+    return out
 
 
 def cpu_baseline(design, pm_state, pc_state, batch_paths, steps=10, warm=2, anomaly_steps=3):
@@ -126,7 +144,7 @@ def cpu_baseline(design, pm_state, pc_state, batch_paths, steps=10, warm=2, anom
     + `steps` timed steps with anomaly detection off (median), then `anomaly_steps` timed steps with it on."""
     from oracle import restatement as R
     # the GPU box gives one GPU's share of the host: 16 cores (more threads than that only oversubscribe)
-    ncores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+    ncores = host_threads_per_rank(1)
     torch.set_num_threads(ncores)
     log(f'cpu oracle on {ncores} threads (os.cpu_count() = {os.cpu_count()})')
     orc = R.OracleTrainer(pm_state, pc_state)
@@ -173,13 +191,40 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def limit_host_threads(world=1):
-    """The GPU box shows 256 CPUs but grants a 16-CPU quota (cgroup cpu.max): a single OpenMP region of torch's CPU
-    side (index packing, link lists) spun up on 256 threads exhausts a 100 ms quota period in a few ms and the whole
-    process is then throttled for the rest of it - 50-70 ms stalls in the middle of a step (measured: cpu.stat
-    nr_throttled).  Keep the host side to the threads it is entitled to."""
+def host_cpu_quota(cgroup_root='/sys/fs/cgroup'):
+    """CPUs this process may use: min(affinity mask, cgroup CPU quota).  cgroup v2 `cpu.max` ("<quota> <period>" or "max
+    <period>"), v1 `cpu/cpu.cfs_quota_us` / `cpu.cfs_period_us` (-1 = unlimited); unreadable files count as no quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    torch.set_num_threads(max(1, min(16, n) // max(1, world)))
+    quota = None
+    try:
+        with open(os.path.join(cgroup_root, 'cpu.max')) as f:
+            q, per = f.read().split()[:2]
+            if q != 'max':
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open(os.path.join(cgroup_root, 'cpu', 'cpu.cfs_quota_us')) as f:
+                q = float(f.read())
+            with open(os.path.join(cgroup_root, 'cpu', 'cpu.cfs_period_us')) as f:
+                per = float(f.read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, int(quota)) if quota is not None and quota >= 1 else n)
+
+
+def host_threads_per_rank(local_world=1, cap=16, cgroup_root='/sys/fs/cgroup'):
+    """Threads one rank gives torch's CPU side.  The GPU box shows 256 CPUs but grants a 16-CPU quota (cgroup cpu.max): a
+    single OpenMP region (index packing, link lists) spun up on 256 threads exhausts a 100 ms quota period in a few ms and
+    the whole process is then throttled for the rest of it - 50-70 ms stalls in the middle of a step (measured: cpu.stat
+    nr_throttled).  All ranks of a node share ONE cgroup, so the quota is divided by the number of local ranks: 8 ranks
+    under a 16-CPU quota get 2 threads each (the timed step's host side is one index pack + one graph replay)."""
+    return max(1, min(cap, host_cpu_quota(cgroup_root) // max(1, int(local_world))))
+
+
+def limit_host_threads(local_world=1):
+    torch.set_num_threads(host_threads_per_rank(local_world))
 
 
 def main():
@@ -217,7 +262,7 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    limit_host_threads(1)            # per rank: the 8-GPU node grants each rank its own share
+    limit_host_threads(int(os.environ.get('LOCAL_WORLD_SIZE', world)))       # the ranks of a node share one CPU quota
     if world != args.gpus:
         log(f'WORLD_SIZE={world} differs from --gpus {args.gpus}: running (and reporting) {world} ranks')
     rank = int(os.environ.get('RANK', '0'))
@@ -296,14 +341,14 @@ def main():
         # every rank runs the instrumented steps (the all-reduce needs all of them); only rank 0 records events
         L = lib.load()
         if rank == 0:
-            L.mmft_prof_reset()
-            L.mmft_prof_enable(1)
+            lib.prof_reset()
+            lib.prof_enable(True)
         nprof = min(args.steps, 3)
         for _i in range(nprof):
             ts.step(sample_paths(designs, args.batch_paths, rng))
         torch.cuda.synchronize()
         if rank == 0:
-            L.mmft_prof_enable(0)
+            lib.prof_enable(False)
     if rank == 0 and not args.no_roofline:
         log('profiled steps done')
         rows = sorted(prof_report(), key=lambda r: -r['ms'])
@@ -339,6 +384,14 @@ def main():
         else:       # the committed counter passes were taken on config B: their bytes per launch say nothing about other sizes
             roofline['traffic'], roofline['traffic_source'] = None, 'PMC table is for config B launches'
 
+        # SURVEY 8(d)'s own count of the aggregation traffic (the MINIMUM a sweep has to move: rows gathered + rows written +
+        # indices), next to `frac`, which prices the bytes the kernel really moves (saved-for-backward rows included)
+        sec8d = sec8d_aggregation(designs, rows, nprof, D=pmodel.gnn.out_feat_dim)
+        roofline['sec8d_aggregation'] = sec8d
+        side = 'fwd' if top['name'].split('<')[0] in SEC8D_FWD else ('bwd' if top['name'].split('<')[0] in SEC8D_BWD else None)
+        roofline['frac_sec8d'] = sec8d[side]['frac_of_hbm_peak'] if side else None
+        zero = [r['name'] for r in rows[:10] if r['bytes'] == 0 and r['flops'] == 0]
+        roofline['top10_without_accounting'] = zero
         roofline.update(kernel=top['name'], launches_per_step=top['launches'] / nprof,
                         avg_launch_us=per_launch_ms * 1e3, share_of_device_time=top['ms'] / total_ms,
                         device_ms_per_step=total_ms / nprof,

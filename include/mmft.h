@@ -49,6 +49,9 @@ int mmft_get_math_mode(void);
 int mmft_prof_enable(int on);
 int mmft_prof_reset(void);
 int mmft_prof_report(char* buf, int cap);
+/* Algorithmic flops / bytes of the calling thread's NEXT instrumented launch that records none itself (the masked
+ * projection and whole-workgroup segment sums: their work depends on per-step run / edge counts only the host has). */
+int mmft_prof_hint(double flops, double bytes);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense layers  --  replaces th.nn.Linear / LeakyReLU inside MLP (src/model.py:10-24), used by
@@ -249,16 +252,6 @@ int mmft_target_rows_begin(float* G, long long ld, const int* idx, int n, int D,
 int mmft_target_rows_end(const int* idx, int n, unsigned char* flags, int device, void* stream);
 /* flags[idx[i]] = value for i < n (seeds the fan-in-cone mask with the step's endpoints) */
 int mmft_mark_rows(const int* idx, int n, unsigned char* flags, int value, int device, void* stream);
-/* Persistent forward sweep: ONE launch for levels 1..L-1 of a mini-batch (the L per-level PathConv.forward calls of
- * src/train.py:490-511).  h must hold the *_self MLP outputs of every node (level 0 already activated); levels
- * are separated by an in-kernel grid barrier (agent-scope release/acquire, bounded spin).  level_ptr[L+1] /
- * level_rows: node ids level-major; counter / error_flag: one device word each (zeroed by the call; error_flag
- * becomes 1 if a barrier wait ran out, in which case h is incomplete).  D = 128, HD = 256 only. */
-int mmft_sweep_fwd_persistent(float* h, float* A, float* LSE, float* HN, const int* in_net_indptr,
-                              const int* in_net_indices, const int* in_cell_indptr, const int* in_cell_indices,
-                              const int* level_ptr, const int* level_rows, int L, const float* w1, const float* b1,
-                              const float* w2, const float* b2, int relu, int D, int HD, int max_level_rows,
-                              unsigned* counter, int* error_flag, int device, void* stream);
 /* dst[i] = src[idx[i]]  /  dst[idx[i]] += src[i] (atomic, duplicates allowed: src/train.py:377-380) */
 int mmft_gather_rows(const float* src, long long lds, const int* idx, int n, int D, float* dst, long long ldd,
                      int device, void* stream);
@@ -463,18 +456,6 @@ long long mmft_outconv_bwd_workspace_bytes(int Nimg, int H, int W, int Ci);
 int mmft_outconv_bwd(const float* x, const float* w, const float* bias, const float* gout, float* dx, float* dw, float* db,
                      int accumulate, int Nimg, int H, int W, int Ci, int mode, float* workspace, long long workspace_bytes,
                      int device, void* stream);
-
-/* ---- streams with a share of the compute units -----------------------------------------------------------------------
- * The step's two independent branches (netlist sweep: src/model.py:176-214; layout U-Net: src/Unet.py:85-113) are
- * replayed on two HIP streams.  mmft_stream_create_cu_mask creates a stream whose kernels may only occupy the CUs whose
- * bit is set in mask[0 .. nwords) (bit i of word i / 32; hipExtStreamCreateWithCUMask); *stream_out receives the
- * hipStream_t as an integer (torch.cuda.ExternalStream takes it).  mmft_device_cu_count: CUs of the device, -1 on error. */
-int mmft_stream_create_cu_mask(int device, const unsigned int* mask, int nwords, long long* stream_out);
-int mmft_stream_destroy(long long stream);
-int mmft_device_cu_count(int device);
-/* Diagnostic for the mask layout: n_wg workgroups of 1024 threads, each holding its CU for spin_ticks of the 100 MHz wall
- * clock; out[i] = (XCC id << 16) | (HW_ID & 0xffff) of workgroup i (HW_ID: cu 11:8, sh 12, se 15:13). */
-int mmft_debug_cu_census(unsigned int* out, int n_wg, int spin_ticks, int device, void* stream);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,26 @@ inline int check_launch(const char* what) {
   return MMFT_OK;
 }
 
+// Kernels that need more dynamic LDS than the 64 KB default get hipFuncAttributeMaxDynamicSharedMemorySize raised once per
+// (launch site, device): the attribute belongs to the device's code object, entry points run on the main thread and on
+// autograd's worker thread, and a refused request must not surface later as an unrelated launch failure.
+struct DynLdsOnce {
+  unsigned long long done = 0;       // bit d: set for device d (devices >= 64 simply repeat the idempotent call)
+};
+inline int ensure_dyn_lds(DynLdsOnce& once, const void* kernel, int bytes, const char* what) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = dev < 64 ? (1ull << dev) : 0ull;
+  if (__atomic_load_n(&once.done, __ATOMIC_ACQUIRE) & bit) return MMFT_OK;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d): %s", what, bytes, hipGetErrorString(e));
+    return MMFT_ERR_LAUNCH;
+  }
+  __atomic_fetch_or(&once.done, bit, __ATOMIC_RELEASE);
+  return MMFT_OK;
+}
+
 #define MMFT_REQUIRE(cond, ...)            \
   do {                                     \
     if (!(cond)) {                         \

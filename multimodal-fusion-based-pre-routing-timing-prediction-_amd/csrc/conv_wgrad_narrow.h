@@ -209,31 +209,31 @@ inline int conv_wgrad_narrow_grid(int Nimg, int H, int W, int Ci) {
 }
 
 template <int CI, int CO, int CS = CI>
-inline void conv_wgrad_narrow_launch_t(const ConvWgradArgs& a, int grid, hipStream_t st) {
+inline int conv_wgrad_narrow_launch_t(const ConvWgradArgs& a, int grid, hipStream_t st) {
   constexpr int TW = wgn_tw(CI);
   using C = ConvWgradCfg<CI, CO, WGN_TH, TW>;
   const double flops = 2.0 * a.N * a.H * a.W * CO * 9.0 * CS;
   const double bytes = 4.0 * a.N * a.H * a.W * (CS + CO);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_narrow_kernel<CI, CO, WGN_TH, TW, CS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    attr_set = true;
-  }
+  static DynLdsOnce once;
+  int rc = ensure_dyn_lds(once, reinterpret_cast<const void*>(&conv3x3_wgrad_narrow_kernel<CI, CO, WGN_TH, TW, CS>), C::LDS_BYTES,
+                          "conv3x3_wgrad_narrow");
+  if (rc) return rc;
   MMFT_LAUNCH_LDS("conv3x3_wgrad_narrow_kernel", flops, bytes, (conv3x3_wgrad_narrow_kernel<CI, CO, WGN_TH, TW, CS>), dim3(grid),
                   dim3(256), C::LDS_BYTES, st, a);
+  return MMFT_OK;
 }
 
 // slabs: grid * Co * 9 * Ci floats.  Returns the launch status; the caller runs slab_reduce over `grid` slabs.
 inline int conv_wgrad_narrow_launch(const float* x, const float* dy, float* slabs, int Nimg, int H, int W, int Ci, int Co,
                                     int grid, hipStream_t st) {
   ConvWgradArgs a{x, dy, slabs, Nimg, H, W, Nimg * (H / WGN_TH) * (W / wgn_tw(Ci))};
-  if (Ci == 3 && Co == 16) conv_wgrad_narrow_launch_t<16, 16, 3>(a, grid, st);
-  else if (Ci == 16 && Co == 16) conv_wgrad_narrow_launch_t<16, 16>(a, grid, st);
-  else if (Ci == 16 && Co == 32) conv_wgrad_narrow_launch_t<16, 32>(a, grid, st);
-  else if (Ci == 32 && Co == 16) conv_wgrad_narrow_launch_t<32, 16>(a, grid, st);
-  else conv_wgrad_narrow_launch_t<32, 32>(a, grid, st);
-  return check_launch("conv3x3_wgrad_narrow");
+  int rc;
+  if (Ci == 3 && Co == 16) rc = conv_wgrad_narrow_launch_t<16, 16, 3>(a, grid, st);
+  else if (Ci == 16 && Co == 16) rc = conv_wgrad_narrow_launch_t<16, 16>(a, grid, st);
+  else if (Ci == 16 && Co == 32) rc = conv_wgrad_narrow_launch_t<16, 32>(a, grid, st);
+  else if (Ci == 32 && Co == 16) rc = conv_wgrad_narrow_launch_t<32, 16>(a, grid, st);
+  else rc = conv_wgrad_narrow_launch_t<32, 32>(a, grid, st);
+  return rc ? rc : check_launch("conv3x3_wgrad_narrow");
 }
 
 }  // namespace mmft

@@ -35,6 +35,16 @@ static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 static ProfRec g_open;
+// Accounting for the NEXT launch of the calling thread whose site cannot know its own work (data-dependent gathers: the
+// host knows the run / edge counts of the step): mmft_prof_hint; consumed by the first launch that records zero counts.
+static thread_local double t_hint_flops = 0.0, t_hint_bytes = 0.0;
+static void take_hint(double* flops, double* bytes) {
+  if (*flops == 0.0 && *bytes == 0.0 && (t_hint_flops != 0.0 || t_hint_bytes != 0.0)) {
+    *flops = t_hint_flops;
+    *bytes = t_hint_bytes;
+    t_hint_flops = t_hint_bytes = 0.0;
+  }
+}
 
 bool prof_on() { return g_prof; }
 static hipEvent_t prof_event() {
@@ -48,11 +58,13 @@ static hipEvent_t prof_event() {
   return e;
 }
 void prof_begin(const char* name, double flops, double bytes, hipStream_t st) {
+  take_hint(&flops, &bytes);
   g_prof_mu.lock();                       // held until prof_end: launches are serialised while profiling
   g_open = ProfRec{name, flops, bytes, prof_event(), prof_event()};
   (void)hipEventRecord(g_open.e0, st);
 }
 void prof_events(const char* name, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1) {
+  take_hint(&flops, &bytes);
   g_prof_mu.lock();
   g_open = ProfRec{name, flops, bytes, prof_event(), prof_event()};
   *e0 = g_open.e0;
@@ -207,6 +219,12 @@ int mmft_get_math_mode(void) { return mmft::math_mode(); }
 int mmft_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(mmft::g_prof_mu);
   mmft::g_prof = on != 0;
+  return MMFT_OK;
+}
+
+int mmft_prof_hint(double flops, double bytes) {
+  mmft::t_hint_flops = flops;
+  mmft::t_hint_bytes = bytes;
   return MMFT_OK;
 }
 

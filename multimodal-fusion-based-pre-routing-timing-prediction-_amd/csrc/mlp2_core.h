@@ -1,4 +1,4 @@
-// Shared pieces of the fused Linear-ReLU-Linear row kernels (mlp2.hip, sweep_persist.hip): register-resident
+// Shared pieces of the fused Linear-ReLU-Linear row kernels (mlp2.hip): register-resident
 // weight panels and the two MFMA phases over a 32-row tile.  128 -> 256 -> 128 widths.
 #pragma once
 #include "gemm_engine.h"

@@ -400,14 +400,10 @@ extern "C" int mmft_mlp2_feat_bwd_bf16(const float* g, long long ldg, const floa
   const long long slab = feat_slab(fin);
   FeatBwdArgs a{g, ldg, x, ldx, row0, n, fin, w1, b1, w2, workspace, slab};
   const double fl = 2.0 * n * (2.0 * fin * MF_HD + 2.0 * MF_HD * MF_D2), by = 4.0 * n * ((double)fin + MF_D2);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp2_feat_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              feat_bwd_lds<1>());
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp2_feat_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              feat_bwd_lds<2>());
-    attr_set = true;
-  }
+  static DynLdsOnce once[2];
+  int arc = fin <= 32 ? ensure_dyn_lds(once[0], reinterpret_cast<const void*>(&mlp2_feat_bwd_kernel<1>), feat_bwd_lds<1>(), "mlp2_feat_bwd_bf16")
+                      : ensure_dyn_lds(once[1], reinterpret_cast<const void*>(&mlp2_feat_bwd_kernel<2>), feat_bwd_lds<2>(), "mlp2_feat_bwd_bf16");
+  if (arc) return arc;
   if (fin <= 32)
     MMFT_LAUNCH_LDS("mlp2_feat_bwd_kernel", fl, by, mlp2_feat_bwd_kernel<1>, dim3(grid), dim3(512), feat_bwd_lds<1>(), st, a);
   else

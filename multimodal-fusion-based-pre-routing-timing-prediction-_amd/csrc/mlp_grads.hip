@@ -256,18 +256,15 @@ extern "C" int mmft_mlp2_first_layer_grads(const float* g, long long ldg, const 
   const size_t lds = (size_t)MG_HD * MG_WS * 4;
   const int ft = (fin + 15) / 16;
   const bool bf = math_mode() == MMFT_MATH_BF16;
-  static bool attr_done[2][4] = {{false, false, false, false}, {false, false, false, false}};
-  auto set_attr = [&](const void* k) {
-    if (!attr_done[bf][ft]) {
-      (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_done[bf][ft] = true;
-    }
-  };
+  static DynLdsOnce once[2][4];
+  int arc = MMFT_OK;
+  auto set_attr = [&](const void* k) { arc = ensure_dyn_lds(once[bf][ft < 3 ? ft : 3], k, (int)lds, "mlp2_first_layer_grads"); };
   const double fl = 2.0 * n * ((double)D2 * HD + (double)HD * ft * 16), by = 4.0 * n * ((double)D2 + HD + fin);
   const dim3 gr(grid), bl(MG_WAVES * 64);
 #define MMFT_MG(FTV, BFV, NAME)                                                                       \
   do {                                                                                                \
     set_attr((const void*)mlp_first_layer_grads_kernel<FTV, BFV>);                                    \
+    if (arc) return arc;                                                                              \
     MMFT_LAUNCH_LDS(NAME, fl, by, (mlp_first_layer_grads_kernel<FTV, BFV>), gr, bl, lds, st, a);      \
   } while (0)
   if (bf) {

@@ -359,12 +359,10 @@ static int path_mask_common(bool fill, const int* paths, const int* lens, int np
   if (npaths == 0) return MMFT_OK;
   DeviceGuard dg(device);
   size_t lds = (size_t)((P + 31) / 32) * 4;
-  static bool attr[2] = {false, false};
-  if (!attr[fill]) {
-    (void)hipFuncSetAttribute(fill ? (const void*)path_mask_kernel<true> : (const void*)path_mask_kernel<false>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 17);
-    attr[fill] = true;
-  }
+  static DynLdsOnce once[2];
+  int arc = ensure_dyn_lds(once[fill ? 1 : 0], fill ? (const void*)path_mask_kernel<true> : (const void*)path_mask_kernel<false>,
+                           1 << 17, "path_mask");
+  if (arc) return arc;
   if (fill)
     hipLaunchKernelGGL(path_mask_kernel<true>, dim3(npaths), dim3(256), lds, (hipStream_t)stream, paths, lens, maxlen,
                        loc_x, loc_y, map_x, map_y, counts, indptr, cols);

@@ -62,12 +62,19 @@ class GradReducer:
             b = gradsink.Bucket(optim.bucket_ranges[i][0], params, self._on_complete)
             b.index = i
             self.buckets.append(b)
-        self.main = None
+        self.main, self.early = None, True
         self.ready, self.events, self.issued = [], [], 0
 
-    def begin(self):
-        """Call right before loss.backward() of an EAGER step (after zero_grad)."""
+    def begin(self, early=True):
+        """Call right before loss.backward() of an EAGER step (after zero_grad).
+
+        early=True hands a bucket to the communication stream at the moment its last member has received its FIRST
+        gradient of the step - correct only when every parameter gets exactly one delivery per step (the whole-sweep
+        step).  The per-level drop-in loop delivers the fusion head's gradients once per LEVEL (and re-reads the head's
+        weights for the next level's input gradient), so there the caller passes early=False and every bucket is reduced
+        in finish(), after backward() has returned."""
         self.main = torch.cuda.current_stream(self.device)
+        self.early = bool(early)
         nb = len(self.buckets)
         self.ready, self.events, self.issued = [False] * nb, [None] * nb, 0
 
@@ -75,8 +82,8 @@ class GradReducer:
         return [self.main] + ([self.side] if self.side is not None else [])
 
     def _on_complete(self, bucket):
-        if self.main is None:                   # not inside an eager step (capture, evaluation, plain backward)
-            return
+        if self.main is None or not self.early:     # not inside an eager step (capture, evaluation, plain backward),
+            return                                  # or a step whose parameters receive several deliveries
         evs = []
         for s in self._streams():
             ev = torch.cuda.Event()

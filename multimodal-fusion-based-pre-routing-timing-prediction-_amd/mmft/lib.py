@@ -113,39 +113,38 @@ def workspace(device, nbytes):
     return buf
 
 
-def cu_count(device=None):
-    dev = torch.cuda.current_device() if device is None else torch.device(device).index or 0
-    n = query('mmft_device_cu_count', dev)
-    if n <= 0:
-        raise RuntimeError('mmft_device_cu_count failed')
-    return n
+PROF_ON = False
 
 
-class MaskedStream:
-    """A HIP stream whose kernels only occupy the given compute units (mmft_stream_create_cu_mask), wrapped for torch:
-    `.stream` is a torch.cuda.ExternalStream.  cus: iterable of CU bit positions."""
+def prof_enable(on=True):
+    """Launch profiler of the library (mmft_prof_*): HIP start / stop events around every instrumented launch."""
+    global PROF_ON
+    load().mmft_prof_enable(1 if on else 0)
+    PROF_ON = bool(on)
 
-    def __init__(self, device, cus):
-        import numpy as np
-        dev = torch.device(device)
-        self.index = dev.index if dev.index is not None else torch.cuda.current_device()
-        n = cu_count(self.index)
-        cus = sorted(set(int(c) for c in cus))
-        if not cus or cus[0] < 0 or cus[-1] >= n:
-            raise ValueError(f'MaskedStream: CU positions must lie in [0, {n})')
-        words = np.zeros((n + 31) // 32, dtype=np.uint32)
-        for c in cus:
-            words[c // 32] |= np.uint32(1 << (c % 32))
-        out = ctypes.c_longlong(0)
-        call('mmft_stream_create_cu_mask', self.index, words.ctypes.data, int(words.shape[0]), ctypes.addressof(out))
-        self.handle = int(out.value)
-        self.cus = cus
-        self.stream = torch.cuda.ExternalStream(self.handle, device=dev)
 
-    def close(self):
-        if self.handle:
-            call('mmft_stream_destroy', self.handle)
-            self.handle = 0
+def prof_hint(flops, nbytes):
+    """Algorithmic work of the calling thread's next launch whose site cannot know it (data-dependent gathers); a no-op
+    unless the launch profiler is on."""
+    if PROF_ON:
+        load().mmft_prof_hint(float(flops), float(nbytes))
+
+
+def prof_reset():
+    load().mmft_prof_reset()
+
+
+def prof_report():
+    """Rows {name, launches, ms, flops, bytes} aggregated per kernel name since the last reset."""
+    L = load()
+    need = L.mmft_prof_report(None, 0)
+    buf = ctypes.create_string_buffer(need + 16)
+    L.mmft_prof_report(ctypes.cast(buf, ctypes.c_void_p), need + 16)
+    rows = []
+    for line in buf.value.decode().splitlines():
+        name, n, ms, fl, by = line.split('\t')
+        rows.append(dict(name=name, launches=int(n), ms=float(ms), flops=float(fl), bytes=float(by)))
+    return rows
 
 
 MATH_MODES = {'f32': 0, 'bf16': 1}

@@ -322,24 +322,6 @@ def _active(active, N):
     return active
 
 
-def sweep_fwd_persistent(h, A, LSE, HN, in_net, in_cell, level_ptr, level_rows, L, w1, b1, w2, b2, relu, max_rows,
-                         counter, err):
-    for t, nm in ((h, 'h'), (A, 'A'), (LSE, 'LSE'), (HN, 'HN'), (w1, 'w1'), (w2, 'w2')):
-        _rows2d(t, nm)
-        if not t.is_contiguous():
-            raise ValueError(f'sweep_fwd_persistent: {nm} must be contiguous')
-    N, D = h.shape
-    if A.shape != h.shape or LSE.shape != h.shape or HN.shape != (N, w1.shape[0]) or tuple(w1.shape) != (HN.shape[1], D) \
-            or tuple(w2.shape) != (D, HN.shape[1]):
-        raise ValueError('sweep_fwd_persistent: inconsistent shapes')
-    _csr(in_net[0], in_net[1], N, 'in_net'); _csr(in_cell[0], in_cell[1], N, 'in_cell')
-    _idx(level_ptr, 'level_ptr', L + 1); _idx(level_rows, 'level_rows')
-    _chk(counter, 'counter', torch.int32); _chk(err, 'err', torch.int32)
-    dev, st = lib.stream_args(h)
-    lib.call('mmft_sweep_fwd_persistent', h, A, LSE, HN, in_net[0], in_net[1], in_cell[0], in_cell[1], level_ptr,
-             level_rows, L, w1, b1, w2, b2, int(relu), D, HN.shape[1], int(max_rows), counter, err, dev, st)
-
-
 def colsum(g, out=None, idx=None, rows=None, accumulate=False):
     _rows2d(g, 'g')
     cols = g.shape[1]
@@ -444,6 +426,8 @@ def scatter_add_rows_det(dst, idx, src):
     # few long segments (a 64-row level table fed by ~10^4 batch rows): a workgroup per destination row
     name = 'mmft_seg_sum_rows_wg' if (idx.numel() >= 16 * R and dst.shape[1] <= 256 and 256 % (dst.shape[1] // 4) == 0) \
         else 'mmft_seg_sum_fwd'
+    if name == 'mmft_seg_sum_rows_wg':
+        lib.prof_hint(float(idx.numel()) * dst.shape[1], idx.numel() * (dst.shape[1] * 4 + 4) + 2.0 * R * dst.shape[1] * 4)
     lib.call(name, src, src.stride(0), indptr, perm.to(torch.int32), None, R, dst.shape[1], dst, dst.stride(0), 1, dev, st)
     return dst
 

@@ -233,6 +233,31 @@ class PinGraph:
         self._level_cache[key] = (nodes, meta)
         return meta
 
+    # Results derived from a whole level schedule are cached per LIST OBJECTS: the entry keeps the lists alive (an id()
+    # can then not be reused by another list while the entry exists), a hit requires `is` on every list plus unchanged
+    # lengths and end elements (guards in-place edits that keep the length), and at most LIST_CACHE_MAX schedules are kept
+    # (per-step host lists, e.g. fan-in cones, would otherwise grow the cache without bound).
+    LIST_CACHE_MAX = 8
+
+    @staticmethod
+    def _lists_key(level_nodes):
+        return (tuple(id(n) for n in level_nodes), tuple(len(n) for n in level_nodes),
+                tuple((n[0], n[-1]) if len(n) else () for n in level_nodes))
+
+    def _lists_hit(self, key, level_nodes):
+        hit = self._level_cache.get(key)
+        if hit is None or len(hit[0]) != len(level_nodes) or not all(a is b for a, b in zip(hit[0], level_nodes)):
+            return None
+        return (hit[1],)
+
+    def _lists_store(self, key, level_nodes, value):
+        order = self.__dict__.setdefault('_lists_order', [])
+        if key not in self._level_cache:
+            order.append(key)
+            while len(order) > self.LIST_CACHE_MAX:
+                self._level_cache.pop(order.pop(0), None)
+        self._level_cache[key] = (tuple(level_nodes), value)
+
     def level_set_is_complete(self, level_nodes):
         """True when the level lists are a complete, well-formed schedule of this graph: every node is in exactly one
         level, every edge runs from a lower to a higher level, net in-edges enter odd levels only and cell in-edges
@@ -241,10 +266,10 @@ class PinGraph:
         truncated list) leaves consumers outside it, whose G / DA rows must read as zero.  Cached per list object."""
         if any(torch.is_tensor(n) for n in level_nodes):
             return False                                        # device-resident lists: not inspected, take the safe path
-        key = ('complete', tuple(id(n) for n in level_nodes), tuple(len(n) for n in level_nodes))
-        hit = self._level_cache.get(key)
+        key = ('complete',) + self._lists_key(level_nodes)
+        hit = self._lists_hit(key, level_nodes)
         if hit is not None:
-            return hit
+            return hit[0]
         lev = np.full(self._n, -1, dtype=np.int64)
         ok, total = True, 0
         for l, nodes in enumerate(level_nodes):
@@ -259,7 +284,7 @@ class PinGraph:
                 s_, d_ = self._coo[et]
                 if s_.size and not bool(((lev[s_] < lev[d_]) & (lev[d_] % 2 == parity) & (lev[d_] >= 1)).all()):
                     ok = False
-        self._level_cache[key] = ok
+        self._lists_store(key, level_nodes, ok)
         return ok
 
     def fold_schedule(self, level_nodes, heavy_in=None, heavy_out=None):
@@ -274,9 +299,10 @@ class PinGraph:
         heavy_out = ops.PAIR_HEAVY_OUT if heavy_out is None else heavy_out
         if not self.level_set_is_complete(level_nodes):
             return None
-        key = ('fold', tuple(id(n) for n in level_nodes), tuple(len(n) for n in level_nodes), heavy_in, heavy_out)
-        if key in self._level_cache:
-            return self._level_cache[key]
+        key = ('fold',) + self._lists_key(level_nodes) + (heavy_in, heavy_out)
+        hit = self._lists_hit(key, level_nodes)
+        if hit is not None:
+            return hit[0]
         lev = np.full(self._n, -1, dtype=np.int64)
         for l, nodes in enumerate(level_nodes):
             lev[np.asarray(nodes, dtype=np.int64)] = l
@@ -304,7 +330,7 @@ class PinGraph:
                 sched.append(dict(range=rng, n=n,
                                   heavy_in=dev_list(v[in_cell_deg[v] > heavy_in]) if (l % 2 == 0 and n) else None,
                                   heavy_out=dev_list(v[out_net_deg[v] > heavy_out]) if (l % 2 == 0 and n) else None))
-        self._level_cache[key] = sched
+        self._lists_store(key, level_nodes, sched)
         return sched
 
     # ------------------------------------------------------------------ construction helpers

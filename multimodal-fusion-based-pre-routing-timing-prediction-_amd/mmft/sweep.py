@@ -446,41 +446,11 @@ def level_forward(conv, graph, cur_nodes, targets, level_id):
 #   * backward = scatter of all target gradients, the reverse pull sweep, batched weight gradients.
 # Same arithmetic as the per-level path (same kernels, same per-row operation order).
 # ------------------------------------------------------------------------------------------------
-# Experimental: one persistent launch (in-kernel grid barriers, weights resident in registers) for the forward level
-# chain.  Correct (tests/test_model_gpu.py::test_persistent_forward_sweep) but SLOWER than per-level launches on
-# MI355X at config B (3.1 ms vs 1.9 ms per forward sweep, tools/bench_sweep.py): a 32-row tile costs ~20 us at one
-# wave per SIMD either way, and the software barrier over 252 workgroups (arrival skew of the slowest tile included)
-# costs more than the ~2 us hardware kernel boundary it replaces.  Off by default.
-PERSISTENT_FORWARD = False
 EDGE_DRIVERS = True                 # folded gather: per-edge driver table (3-deep load chain, four edges in flight)
 FEAT_MLP_NO_HIDDEN = True           # bf16 mode: fc_cell_self / fc_net_self as one kernel each way, hidden activations recomputed
 FUSE_LEVEL_FWD = True               # bf16 mode: folded gather + fused MLP of a level pair in one launch (mmft_level_fwd_bf16)
 FOLD_LEVELS = True                  # folded forward chain (one gather per (net, cell) level PAIR) when the graph allows it
 FUSED_FIRST_LAYER_GRADS = True      # mmft_mlp2_first_layer_grads for the *_self MLPs (False: dgrad GEMM + wgrad GEMM)
-
-
-def _persist_state(graph, level_rows):
-    """Level table + barrier words for mmft_sweep_fwd_persistent, cached on the graph (the level lists are static)."""
-    key = tuple(int(r.data_ptr()) for r in level_rows) + tuple(int(r.numel()) for r in level_rows)
-    ps = graph.__dict__.get('_persist')
-    if ps is None or ps['key'] != key:
-        dev = graph.device
-        counts = [int(r.numel()) for r in level_rows]
-        ptr = torch.tensor([0] + list(torch.tensor(counts).cumsum(0).tolist()), dtype=torch.int32, device=dev)
-        rows = torch.cat([r for r in level_rows]) if sum(counts) else torch.zeros(1, dtype=torch.int32, device=dev)
-        ps = dict(key=key, ptr=ptr, rows=rows.contiguous(), max_rows=max(counts[1:]) if len(counts) > 1 else 0,
-                  counter=torch.zeros(1, dtype=torch.int32, device=dev), err=torch.zeros(1, dtype=torch.int32, device=dev),
-                  err_host=torch.zeros(1, dtype=torch.int32).pin_memory())
-        graph.__dict__['_persist'] = ps
-    return ps
-
-
-def check_persistent_error(graph):
-    """Raise if a previous persistent sweep reported a barrier time-out (host read of a pinned word, no sync)."""
-    ps = graph.__dict__.get('_persist')
-    if ps is not None and int(ps['err_host'][0]) != 0:
-        raise RuntimeError('persistent sweep kernel: a grid-barrier wait ran out (workgroups not co-resident?); '
-                           'results of that step are invalid - set mmft.sweep.PERSISTENT_FORWARD = False')
 
 
 class SweepFn(torch.autograd.Function):
@@ -520,7 +490,7 @@ class SweepFn(torch.autograd.Function):
             else:
                 _linear_rows(st.cell_feat, w1c, b1c, st.HS, rc2, act=ops.ACT_RELU)
                 _linear_rows(st.HS, w2c, b2c, st.h, rc2)
-        fold = st.fold if (FOLD_LEVELS and not PERSISTENT_FORWARD and st.attn is None) else None
+        fold = st.fold if (FOLD_LEVELS and st.attn is None) else None
         if fold is not None:
             st.PRE = st._buf('PRE', st.D)     # fc_net_self outputs live apart from h: the folded gather updates h in place
         if rn is not None:                                                               # fc_net_self, all net nodes
@@ -530,14 +500,7 @@ class SweepFn(torch.autograd.Function):
                 _linear_rows(st.net_feat, w1n, b1n, st.HS, rn, act=ops.ACT_RELU)
                 _linear_rows(st.HS, w2n, b2n, st.PRE if fold is not None else st.h, rn)
         in_net, in_cell = g.csr('in', 'net'), g.csr('in', 'cell')
-        persistent = PERSISTENT_FORWARD and ops.mlp2_fusable(st.D, st.Hd, st.D) and len(level_rows) > 1 and st.attn is None
-        if persistent:
-            check_persistent_error(g)
-            ps = _persist_state(g, level_rows)
-            ops.sweep_fwd_persistent(st.h, st.A, st.LSE, st.HN, in_net, in_cell, ps['ptr'], ps['rows'], len(level_rows),
-                                     w1g, b1g, w2g, b2g, st.relu, ps['max_rows'], ps['counter'], ps['err'])
-            ps['err_host'].copy_(ps['err'], non_blocking=True)
-        if fold is not None and not persistent:
+        if fold is not None:
             # folded chain: one gather launch per (net level l - 1, cell level l) pair + the fused MLP of the cell level
             L = len(level_rows)
             drv = g.cell_edge_drivers() if EDGE_DRIVERS else None
@@ -567,7 +530,7 @@ class SweepFn(torch.autograd.Function):
                 if has_cell:
                     _cell_neigh_fwd(st, level_rows[level_id], w1g, b1g, w2g, b2g, act)
         for level_id, rows in enumerate(level_rows):
-            if persistent or fold is not None or level_id == 0 or not rows.numel():
+            if fold is not None or level_id == 0 or not rows.numel():
                 continue
             meta = st.level_meta[level_id] if st.level_meta else None
             spec = meta['range'] if (meta and meta['range']) else rows       # contiguous levels: no index array

@@ -272,7 +272,9 @@ class TrainStep:
         loss = self.loss(hats, ends_d)
         self.optim.zero_grad()
         if self.reducer is not None:
-            self.reducer.begin()
+            # one delivery per parameter and step only in the whole-sweep form; the per-level loop adds into the head's
+            # gradients once per level, so its buckets are reduced after backward() has returned
+            self.reducer.begin(early=(self.mode == 'sweep'))
             loss.backward()
             self.reducer.finish()            # buckets not yet reduced; compute stream waits for the last Adam
         elif self.world_size > 1:
@@ -314,15 +316,10 @@ class GraphedTrainStep:
     the one-GPU default.  No collective is ever captured.
     """
 
-    def __init__(self, ts, example_path_ids, warmup=3, pieces=None, cu_split=None):
+    def __init__(self, ts, example_path_ids, warmup=3, pieces=None):
         if not ts.fused or ts.mode != 'sweep':
             raise ValueError('GraphedTrainStep needs mode="sweep" and the fused optimizer')
         self.ts = ts
-        if cu_split is None and os.environ.get('MMFT_CU_SPLIT'):
-            cu_split = float(os.environ['MMFT_CU_SPLIT'])
-        self.cu_split = cu_split if (cu_split and 0.0 < cu_split < 1.0) else None
-        if self.cu_split and pieces is None:
-            pieces = True
         b = ts.batch
         if pieces is None:
             pieces = ts.world_size > 1          # see the class docstring: the cuts pay for themselves under data parallelism
@@ -402,16 +399,6 @@ class GraphedTrainStep:
             torch.autograd.backward(feat_out, grad_tensors=feat_leaf.grad, inputs=cnn_params)
         self._keep = (h_out, h_leaf, feat_out, feat_leaf, pmap)
         self._ev = [torch.cuda.Event() for _ in range(6)]
-        # CU partition between the two branches (cu_split = share of the CUs given to the netlist sweep; None: ordinary
-        # streams).  Consecutive mask bits go to different XCDs / shader engines, so each branch keeps a share of every
-        # XCD and all eight L2s.
-        self.sweep_q = self.unet_q = None
-        if self.cu_split:
-            from . import lib as _lib
-            n = _lib.cu_count(ts.device)
-            k = max(8, min(n - 8, int(round(n * self.cu_split / 8)) * 8))
-            self._masked = (_lib.MaskedStream(ts.device, range(0, k)), _lib.MaskedStream(ts.device, range(k, n)))
-            self.sweep_q, self.unet_q = self._masked[0].stream, self._masked[1].stream
 
     def step(self, path_ids_per_design):
         """Host side of a step: pack the sampled endpoints (pinned staging slot -> one async H2D copy), replay.  No
@@ -426,8 +413,6 @@ class GraphedTrainStep:
             else:
                 ts.optim.note_replay()
             return self.loss, self.hats, sel[4].tolist()
-        if self.sweep_q is not None:
-            return self._step_partitioned(sel)
         main, side = torch.cuda.current_stream(ts.device), ts.side
         e0, eA, eH, ebA = self._ev[:4]
         e0.record(main)                          # the endpoint indices are in place (and the previous step's Adam is done)
@@ -453,51 +438,13 @@ class GraphedTrainStep:
             ts.optim.step()
         return self.loss, self.hats, sel[4].tolist()
 
-    def _step_partitioned(self, sel):
-        """Pieces replayed on two CU-masked streams: A / bA on the sweep's share, B / bB on the U-Net's share, the
-        joined parts (head, optimizer) on the caller's stream with the whole chip."""
-        ts = self.ts
-        main, qa, qb = torch.cuda.current_stream(ts.device), self.sweep_q, self.unet_q
-        e0, eA, eB, eH, ebA, ebB = self._ev
-        e0.record(main)
-        qa.wait_event(e0)
-        qb.wait_event(e0)
-        with torch.cuda.stream(qa):
-            self.gA.replay()
-            eA.record(qa)
-        with torch.cuda.stream(qb):
-            self.gB.replay()
-            eB.record(qb)
-        main.wait_event(eA)
-        main.wait_event(eB)
-        self.gH.replay()
-        eH.record(main)
-        qa.wait_event(eH)
-        qb.wait_event(eH)
-        if ts.reducer is not None:
-            ts.reducer.reduce_bucket(0, [eH])
-        with torch.cuda.stream(qa):
-            self.gbA.replay()
-            ebA.record(qa)
-        with torch.cuda.stream(qb):
-            self.gbB.replay()
-            ebB.record(qb)
-        main.wait_event(ebA)
-        main.wait_event(ebB)
-        if ts.reducer is not None:
-            ts.reducer.reduce_rest_and_join(main)
-        else:
-            ts.optim.step()
-        return self.loss, self.hats, sel[4].tolist()
-
     def time_pieces(self, reps=10):
         """Diagnostic: every piece replayed ALONE on the stream it is assigned to (ms each), plus A | B and bA | bB
         together.  Only for pieces mode; leaves the parameters untouched (no optimizer step) but overwrites gradients."""
         import time
         ts = self.ts
         main = torch.cuda.current_stream(ts.device)
-        qa = self.sweep_q if self.sweep_q is not None else ts.side
-        qb = self.unet_q if self.unet_q is not None else main
+        qa, qb = ts.side, main
 
         def run(pairs):
             def once():

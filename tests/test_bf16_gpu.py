@@ -311,3 +311,48 @@ def test_feature_mlp_without_hidden_tensor(dev, fin, n, row0, representable):
     assert rel_err(db2, g[sl].double().sum(0)) < 1e-5             # from the fp32 staging registers: exact in both cases
     assert rel_err(dw1, dH.T @ xb[sl]) < scale
     assert rel_err(db1, ((gb[sl] @ w2b) * (pre > 0)).sum(0)) < scale
+
+
+def test_full_size_config_b_in_bf16_mode(dev):
+    """the configuration bench.py times - config B at full size (8 x 65 536 nodes, 64 levels, 256 x 256
+    tiles, 1350 endpoints per design) in bf16 math mode - under test: two independent runs of two optimizer steps end
+    bitwise equal, the replayed HIP graph follows the eager step, every parameter stays finite, the fused level kernel and
+    the tile convolutions are the kernels that ran, and the first step's predictions are within the stated 5e-2 (of the
+    predictions' scale) of the fp32 run of the same step."""
+    from mmft.synth import synth_design
+    from mmft.train import build_models, TrainStep, GraphedTrainStep
+    designs = [synth_design(N=65536, L=64, tile=256, seed=9294 + i) for i in range(8)]
+    rng = np.random.default_rng(6)
+    batches = [[rng.permutation(d.num_paths)[:1350] for d in designs] for _ in range(2)]
+    L = lib.load()
+
+    def run(kind, mode, profile=False):
+        with lib.math_mode(mode):
+            pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=9294)
+            ts = TrainStep(pmodel, cnn, designs, dev)
+            stepper = GraphedTrainStep(ts, batches[0], warmup=0) if kind == 'graph' else ts
+            if profile:
+                lib.prof_reset()
+                lib.prof_enable(True)
+            first = stepper.step(batches[0])
+            hats0 = first[1].clone()
+            out = stepper.step(batches[1])
+            torch.cuda.synchronize()
+            names = {r['name'] for r in lib.prof_report()} if profile else set()
+            if profile:
+                lib.prof_enable(False)
+            res = (float(out[0]), out[1].clone(), ts.optim.flat_param.clone(), hats0, first[2])
+            del ts, stepper, pmodel, cnn
+        return res, names
+
+    (a, names), (b, _), (g, _) = run('eager', 'bf16', profile=True), run('eager', 'bf16'), run('graph', 'bf16')
+    # the kernels BENCH times are the ones this test ran
+    assert any(n.startswith('level_fwd_bf16_kernel') for n in names), sorted(names)
+    assert any(n.startswith('conv3x3_tile') for n in names) and any(n.startswith('conv3x3_wgrad_narrow') for n in names), sorted(names)
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])               # bitwise run to run
+    assert abs(g[0] - a[0]) < 1e-4 * abs(a[0]) and rel_err(g[1], a[1]) < 1e-4                 # graph replay = eager
+    assert bool(torch.isfinite(a[2]).all()) and bool(torch.isfinite(a[1]).all())
+    (f, _) = run('eager', 'f32')
+    assert f[4] == a[4]                                                                       # same endpoints, same order
+    assert rel_err(a[3], f[3]) < 5e-2                      # stated bf16 tolerance: first-step predictions vs the fp32 run
+    assert rel_err(a[3], f[3]) > 1e-6                      # ... and bf16 mode really was a different arithmetic

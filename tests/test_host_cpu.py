@@ -209,3 +209,72 @@ def test_bench_pmc_table_lookup(tmp_path, monkeypatch):
     path.write_text(json.dumps(table))
     val, why = bench.pmc_traffic('level_fwd_bf16_kernel')
     assert val is None and 'stamp' in why
+
+
+def test_schedule_caches_hold_their_lists_and_stay_bounded():
+    """level_set_is_complete / fold_schedule cache per list OBJECTS.  The entry keeps the lists (no id() reuse),
+    an equal-length in-place edit of a list is not answered from the cache, and the cache is bounded."""
+    d = synth_design(N=512, L=8, tile=16, seed=3, end_frac=0.5)
+    g = PinGraph.from_synth(d)
+    levels = [lv.tolist() for lv in d.levels]
+    assert g.level_set_is_complete(levels) is True
+    assert g.level_set_is_complete(levels) is True                        # hit
+    g.fold_schedule(levels)            # (None here: the raw synthetic ids are not level-major; the entry is cached all the same)
+    # same objects, same lengths, other content: level 2's first node replaced by level 4's first node (now listed twice)
+    keep = levels[2][0]
+    levels[2][0] = levels[4][0]
+    assert g.level_set_is_complete(levels) is False
+    assert g.fold_schedule(levels) is None
+    levels[2][0] = keep
+    assert g.level_set_is_complete(levels) is True
+    # equal copies are other objects: answered by inspection, and every entry pins its lists
+    for _ in range(3 * PinGraph.LIST_CACHE_MAX):
+        assert g.level_set_is_complete([list(lv) for lv in levels]) is True
+    n_sched = sum(1 for k in g._level_cache if k[0] in ('complete', 'fold'))
+    assert n_sched <= PinGraph.LIST_CACHE_MAX
+    for k, (refs, _) in g._level_cache.items():
+        if k[0] in ('complete', 'fold'):
+            assert tuple(id(r) for r in refs) == k[1]
+
+
+def test_bench_host_threads_follow_the_cgroup_quota(tmp_path):
+    """the ranks of one node share one CPU quota, so a rank takes quota / local_world threads."""
+    import os
+    import bench
+    aff = len(os.sched_getaffinity(0))
+    v2 = tmp_path / 'v2'
+    v2.mkdir()
+    (v2 / 'cpu.max').write_text('1600000 100000\n')                      # the GPU box: 16 CPUs of 256 visible
+    want = min(16, aff)
+    assert bench.host_cpu_quota(str(v2)) == want
+    assert bench.host_threads_per_rank(1, cgroup_root=str(v2)) == want
+    assert bench.host_threads_per_rank(8, cgroup_root=str(v2)) == max(1, want // 8)
+    assert bench.host_threads_per_rank(64, cgroup_root=str(v2)) == 1
+    (v2 / 'cpu.max').write_text('max 100000\n')
+    assert bench.host_cpu_quota(str(v2)) == aff                          # no quota: the affinity mask
+    v1 = tmp_path / 'v1'
+    (v1 / 'cpu').mkdir(parents=True)
+    (v1 / 'cpu' / 'cpu.cfs_quota_us').write_text('400000\n')
+    (v1 / 'cpu' / 'cpu.cfs_period_us').write_text('100000\n')
+    assert bench.host_cpu_quota(str(v1)) == min(4, aff)
+    (v1 / 'cpu' / 'cpu.cfs_quota_us').write_text('-1\n')
+    assert bench.host_cpu_quota(str(v1)) == aff
+    assert bench.host_cpu_quota(str(tmp_path / 'missing')) == aff
+
+
+def test_bench_sec8d_formula():
+    """bench.sec8d_aggregation: SURVEY 8(d)'s aggregation bytes from the design itself, divided over the launches of the
+    kernels that carry them."""
+    import bench
+    d = synth_design(N=2048, L=12, tile=16, seed=4, end_frac=0.25)
+    E = d.net_src.shape[0] + d.cell_src.shape[0]
+    Nd = d.N - len(d.levels[0])
+    rows = [dict(name='level_fwd_bf16_kernel', launches=10, ms=0.2, flops=1.0, bytes=1.0),
+            dict(name='level_bwd_pull_kernel', launches=24, ms=0.3, flops=1.0, bytes=1.0),
+            dict(name='adam_kernel', launches=2, ms=0.1, flops=0.0, bytes=1.0)]
+    r = bench.sec8d_aggregation([d, d], rows, nprof=2, D=128)
+    assert r['fwd']['bytes_per_step'] == 2 * (4 * 128 * (E + Nd) + 4 * E + 4 * (Nd + d.L))
+    assert r['bwd']['bytes_per_step'] == 2 * (4 * 128 * (3 * E + 2 * Nd) + 4 * E)
+    assert r['fwd']['launches_per_step'] == 5 and r['bwd']['launches_per_step'] == 12
+    assert abs(r['fwd']['achieved_gbs'] - r['fwd']['bytes_per_step'] / 0.1e-3 / 1e9) < 1e-6
+    assert abs(r['fwd']['frac_of_hbm_peak'] - r['fwd']['achieved_gbs'] / bench.PEAK_HBM_GBS) < 1e-12

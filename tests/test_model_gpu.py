@@ -641,36 +641,6 @@ def test_training_trajectory_vs_oracle(dev):
     assert abs(m["endpoint_slack_mae"] - mae_o) < 2e-2 * max(mae_o, 1e-6) + 1e-4
 
 
-def test_persistent_forward_sweep(dev):
-    """The experimental persistent forward sweep (in-kernel grid barriers, write-through h rows) gives the same
-    embeddings, predictions and gradients as the per-level launches."""
-    from mmft.synth import synth_design
-    from mmft.train import build_models, TrainStep
-    from mmft.fusion import mse_loss
-    from mmft import sweep
-    designs = [synth_design(N=8192, L=20, tile=32, seed=500 + i, end_frac=0.25) for i in range(3)]
-    ids = [np.random.default_rng(i).permutation(d.num_paths)[:50].tolist() for i, d in enumerate(designs)]
-    res = {}
-    try:
-        for flag in (False, True):
-            sweep.PERSISTENT_FORWARD = flag
-            pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=7)
-            ts = TrainStep(pmodel, cnn, designs, dev, overlap=False)
-            hats, ends_d, _ = ts.forward(ids)
-            loss = mse_loss(hats, ts.batch.arrival[ends_d.long()].squeeze(-1))
-            ts.optim.zero_grad()
-            loss.backward()
-            torch.cuda.synchronize()
-            if flag:
-                assert int(ts.batch.graph._persist['err'].item()) == 0, 'grid barrier timed out'
-            res[flag] = (hats.detach().clone(), ts.h.clone(), ts.optim.flat_grad.clone())
-    finally:
-        sweep.PERSISTENT_FORWARD = False
-    close(res[True][1], res[False][1], 1e-6, 'h')
-    close(res[True][0], res[False][0], 1e-6, 'hats')
-    close(res[True][2], res[False][2], 1e-5, 'grads')
-
-
 def test_reference_style_training_loop(dev):
     """The reference's own loop shape (src/train.py:431-443,461-562) run verbatim against the drop-in modules:
     torch.optim.Adam over chain(model, cnn), nn.MSELoss, DataLoader(PathDataset) batches, dense

@@ -153,7 +153,7 @@ def test_partial_schedule_on_fresh_and_stale_buffers_vs_oracle(dev):
 
 
 # ------------------------------------------------------------------------------------------------ data parallel
-def _dp_worker(rank, world, port, out_dir):
+def _dp_worker(rank, world, port, out_dir, mode='sweep'):
     for p in (ROOT, PKG):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -167,7 +167,7 @@ def _dp_worker(rank, world, port, out_dir):
     from mmft.train import build_models, TrainStep, GraphedTrainStep
     d = synth_design(N=2048, L=12, tile=32, seed=design_seeds(rank, 1)[0], end_frac=0.25)
     pmodel, cnn = build_models(map_size=d.map_size, device=dev, seed=21)       # identical parameters on every rank
-    ts = TrainStep(pmodel, cnn, [d], dev, world_size=world)
+    ts = TrainStep(pmodel, cnn, [d], dev, world_size=world, mode=mode)
     rng = np.random.default_rng(100 + rank)
     batches = [[rng.permutation(d.num_paths)[:24].tolist()] for _ in range(5)]
     names = [n for n, _ in list(pmodel.named_parameters()) + [('cnn.' + k, v) for k, v in cnn.named_parameters()]]
@@ -179,9 +179,13 @@ def _dp_worker(rank, world, port, out_dir):
     out['params1'] = {n: p.detach().cpu().clone()
                       for n, p in list(pmodel.named_parameters()) + [('cnn.' + k, v) for k, v in cnn.named_parameters()]}
     losses = [float(ts.step(batches[1])[0])]
-    gs = GraphedTrainStep(ts, batches[2], warmup=0)         # replayed forward + backward, reducer behind every replay
-    for ids in batches[2:]:
-        losses.append(float(gs.step(ids)[0]))
+    if mode == 'sweep':
+        gs = GraphedTrainStep(ts, batches[2], warmup=0)     # replayed forward + backward, reducer behind every replay
+        for ids in batches[2:]:
+            losses.append(float(gs.step(ids)[0]))
+    else:                                                   # the per-level loop is not captured: eager steps
+        for ids in batches[2:]:
+            losses.append(float(ts.step(ids)[0]))
     torch.cuda.synchronize()
     out['losses'] = losses
     out['steps'] = ts.optim.step_count
@@ -265,6 +269,44 @@ def test_data_parallel_two_ranks_share_one_gpu(dev, tmp_path):
     assert num / (den_a * den_b) ** 0.5 > 0.97
 
 
+def test_data_parallel_dropin_mode(dev, tmp_path):
+    """TrainStep(mode='dropin', world_size=2).  The per-level loop delivers the fusion head's gradients once
+    per LEVEL, so its bucket must not be handed to the communication stream at the first delivery: every bucket is
+    reduced after backward() has returned.  Step-1 reduced gradients = the fp64 oracle's mean of the per-design
+    gradients, the first Adam step is exact given that gradient, the replicas stay bitwise identical for 5 steps."""
+    import torch.multiprocessing as mp
+    from mmft.dist import design_seeds
+    from mmft.synth import synth_design
+    from mmft.train import build_models
+    port = 29600 + ((os.getpid() + 977) % 2000)
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path), 'dropin'), nprocs=2, join=True)
+    r = [torch.load(os.path.join(tmp_path, f'r{k}.pt'), weights_only=False) for k in range(2)]
+    assert r[0]['steps'] == r[1]['steps'] == 5 and r[0]['dev_steps'] == [5, 5]
+    for n in r[0]['params']:
+        assert torch.equal(r[0]['params'][n], r[1]['params'][n]), n
+    ds = [synth_design(N=2048, L=12, tile=32, seed=design_seeds(k, 1)[0], end_frac=0.25) for k in range(2)]
+    pmodel, cnn = build_models(map_size=ds[0].map_size, device='cpu', seed=21)
+    orc = R.OracleTrainer({k: v.clone() for k, v in pmodel.state_dict().items()},
+                          {k: v.clone() for k, v in cnn.state_dict().items()}, dtype=torch.float64)
+    loss = 0
+    for k in range(2):
+        hats, tl, _ = R.sweep_forward(orc.pm, orc.pc, ds[k], R.design_csr(ds[k]), r[k]['batches'][0][0],
+                                      update_running=False, dtype=torch.float64)
+        arr = torch.from_numpy(ds[k].arrival_time).double()[torch.tensor(tl)].squeeze(-1)
+        loss = loss + torch.nn.functional.mse_loss(hats, arr) / 2
+    loss.backward()
+    p0 = dict(list(pmodel.named_parameters()) + [('cnn.' + k, v) for k, v in cnn.named_parameters()])
+    for n, gref in r[0]['grad1'].items():
+        o = orc.pc[n[4:]] if n.startswith('cnn.') else orc.pm[n]
+        if o.grad is None:
+            assert gref is None or float(gref.abs().max()) == 0.0, n
+            continue
+        assert rel_err(gref, o.grad) < 1e-4, n          # every level's head gradient is in the reduced buffer
+        assert torch.equal(gref, r[1]['grad1'][n]), n
+        want = p0[n].detach().double() - 1e-3 * gref.double() / (gref.double().abs() + 1e-8)
+        assert float((r[0]['params1'][n].double() - want).abs().max()) < 2e-7, n
+
+
 def test_bench_self_launches_its_ranks(dev):
     """`python bench.py --gpus 2` without torchrun: the process starts the two ranks itself before touching the GPU
     (here rehearsed over gloo, both ranks on the one GPU) and rank 0 prints the single JSON line with n_gpus = 2."""
@@ -282,14 +324,24 @@ def test_bench_self_launches_its_ranks(dev):
     assert abs(j['value'] - 2 * 1 * 3 / (j['ms_per_step'] * 3 / 1e3)) / j['value'] < 1e-6      # whole-job designs / s
 
 
-def test_config_b_batch_of_eight_vs_oracle(dev):
+@pytest.mark.parametrize('seeds', [(800, 801, 802, 803, 804, 805, 806, 807), (800, 801, 802, 803, 804, 805, 808, 807)],
+                         ids=['with_pool_tie', 'no_tie'])
+def test_config_b_batch_of_eight_vs_oracle(dev, seeds):
     """The bench's step shape - EIGHT designs merged block-diagonally in one step (per-image BatchNorm statistics, same-index
     levels concatenated, one MSE over all endpoints) - at a reduced node count against the fp64 oracle run design by
-    design: predictions, loss and gradients (= the mean of the per-design gradients)."""
+    design: predictions, loss and gradients (= the mean of the per-design gradients).
+
+    CNN gradients (tools/diag_batch8_grad.py, profiles/r03_diag_batch8_grad.txt): on seeds 800..807 the
+    image of design 806 has ONE 2x2 max-pool window (in front of down3, channel 49) whose two largest values differ by
+    1.2e-6 relative - inside fp32 rounding of the activation - so every fp32 evaluation (torch's own CPU kernels, this
+    library one image at a time, this library on the batch of eight) routes that window's gradient to the other pixel than
+    fp64 does and sits 4e-2 (max norm, down2's second convolution) from the fp64 gradient, while agreeing with each other
+    to 2e-6.  The bound is therefore "no further from fp64 than twice what torch's fp32 CPU path is" with a floor of 1e-4;
+    the second parameter set swaps that design for seed 808: no tie, and every CNN gradient holds 1e-4 against fp64."""
     from mmft.fusion import mse_loss
     from mmft.synth import synth_design
     from mmft.train import build_models, TrainStep
-    designs = [synth_design(N=2048, L=12, tile=64, seed=800 + i, end_frac=0.25) for i in range(8)]
+    designs = [synth_design(N=2048, L=12, tile=64, seed=s, end_frac=0.25) for s in seeds]
     pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=23)
     pm_state = {k: v.detach().cpu().clone() for k, v in pmodel.state_dict().items()}
     pc_state = {k: v.detach().cpu().clone() for k, v in cnn.state_dict().items()}
@@ -300,14 +352,19 @@ def test_config_b_batch_of_eight_vs_oracle(dev):
     loss = mse_loss(hats, ts.batch.arrival[ends_d.long()].squeeze(-1))
     ts.optim.zero_grad()
     loss.backward()
-    orc = R.OracleTrainer(pm_state, pc_state, dtype=torch.float64)
-    total, per_design = 0, {}
-    for i, d in enumerate(designs):
-        h_o, tl, _ = R.sweep_forward(orc.pm, orc.pc, d, R.design_csr(d), ids[i], update_running=False, dtype=torch.float64)
-        arr = torch.from_numpy(d.arrival_time).double()[torch.tensor(tl)].squeeze(-1)
-        total = total + torch.nn.functional.mse_loss(h_o, arr) / 8
-        per_design[i] = (h_o.detach(), [t + int(ts.batch.node_off[i]) for t in tl])
-    total.backward()
+
+    def oracle(dtype):
+        orc = R.OracleTrainer(pm_state, pc_state, dtype=dtype)
+        total, per_design = 0, {}
+        for i, d in enumerate(designs):
+            h_o, tl, _ = R.sweep_forward(orc.pm, orc.pc, d, R.design_csr(d), ids[i], update_running=False, dtype=dtype)
+            arr = torch.from_numpy(d.arrival_time).to(dtype)[torch.tensor(tl)].squeeze(-1)
+            total = total + torch.nn.functional.mse_loss(h_o, arr) / 8
+            per_design[i] = (h_o.detach(), [t + int(ts.batch.node_off[i]) for t in tl])
+        total.backward()
+        return orc, total, per_design
+    orc, total, per_design = oracle(torch.float64)
+    orc32, _, _ = oracle(torch.float32)                     # torch's own fp32 CPU arithmetic on the same eight designs
     assert abs(float(loss) - float(total)) < 1e-4 * float(total)
     # the merged batch orders its endpoints by level, then design: compare through the endpoint ids
     pos = {int(e): k for k, e in enumerate(ends_h.tolist())}
@@ -317,17 +374,15 @@ def test_config_b_batch_of_eight_vs_oracle(dev):
     for k, prm in pmodel.named_parameters():
         if orc.pm[k].grad is not None:
             assert rel_err(prm.grad, orc.pm[k].grad) < 2e-4, k
-    # the U-Net's gradients pass through 14 per-image BatchNorm layers (statistics over 64 pixels at the deepest stage of
-    # this 64 x 64 tile) in front of scale-invariant convolutions: fp32 vs fp64 rounding is amplified by the cancellation
-    # in those layers and grows towards the input (measured 5e-3 .. 4e-2 in max norm on single convolutions, below 1e-3 on the median
-    # layer); the direction is checked separately
-    errs = []
+    worst_cpu = 0.0
     for k, prm in cnn.named_parameters():
-        a, b = prm.grad.double().flatten().cpu(), orc.pc[k].grad.flatten()
-        assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.9999, k
-        errs.append(rel_err(prm.grad, orc.pc[k].grad))
-        assert errs[-1] < 0.1, k          # max-norm; the direction bound above is the sharp one (cos > 0.9999 = 1.4e-2 in L2)
-    assert sorted(errs)[len(errs) // 2] < 1e-3
+        e_hip, e_cpu = rel_err(prm.grad, orc.pc[k].grad), rel_err(orc32.pc[k].grad, orc.pc[k].grad)
+        worst_cpu = max(worst_cpu, e_cpu)
+        assert e_hip < max(1e-4, 2 * e_cpu), (k, e_hip, e_cpu)
+    if seeds[6] == 808:
+        assert worst_cpu < 1e-4               # no decision flips in this set: the 1e-4 floor was the bound on every layer
+    else:
+        assert worst_cpu > 1e-3               # the tie is real: torch's fp32 path is this far from fp64 by itself
 
 
 def test_full_size_config_b_step_is_deterministic(dev):
