@@ -131,6 +131,15 @@ int mmft_level_fwd_bf16(float* h, const float* pre, long long ld, int D, const i
                         const void* w2_bf16, const float* b2, float* hid_out, long long ldhid, int relu,
                         const unsigned char* active, const int* in_cell_driver, long long alg_bytes, int device,
                         void* stream);
+/* The same launch with the per-edge index chain replaced by a static SLOT table (fan-in <= 4 on every cell row of the level,
+ * contiguous row ranges): slots[v] = int[8] = the rows of h to read for v's four in-edges (< 0: no edge) and the rows of
+ * `pre` to add (< 0: the edge's value is the h row itself; >= 0: relu(h[hrow] + pre[prow]), the net of level l - 1
+ * recomputed from its single driver); net_driver[u] = the driver row of net u.  Workgroup b gathers + transforms cell rows
+ * 16 b .. and writes net rows 16 b .. of level l - 1 (src/model.py:88-116,138-146). */
+int mmft_level_fwd_slots(float* h, const float* pre, long long ld, int D, const int* slots, const int* net_driver, int net_row0,
+                         int n_net, int cell_row0, int n_cell, float* A, float* LSE, const void* w1_bf16, const float* b1,
+                         const void* w2_bf16, const float* b2, float* hid_out, long long ldhid, int relu,
+                         const unsigned char* active, long long alg_bytes, int device, void* stream);
 /* MMFT_MATH_BF16: the feature MLPs fc_cell_self / fc_net_self (Linear(fin, 256)-ReLU-Linear(256, 128) over the contiguous node
  * rows row0 .. row0 + n - 1; src/model.py:48-51,66-67,148-153,186-189) WITHOUT a stored hidden tensor.
  *   fwd: out[row] = (relu)(W2 relu(W1 x[row] + b1) + b2); x [.][ldx >= fin] and out [.][ldout] are indexed by NODE id.
@@ -456,6 +465,60 @@ long long mmft_outconv_bwd_workspace_bytes(int Nimg, int H, int W, int Ci);
 int mmft_outconv_bwd(const float* x, const float* w, const float* bias, const float* gout, float* dx, float* dw, float* db,
                      int accumulate, int Nimg, int H, int W, int Ci, int mode, float* workspace, long long workspace_bytes,
                      int device, void* stream);
+
+/* ---- bf16-STORAGE layout U-Net (bf16 math mode; BASELINE config B "bf16 storage / fp32 accumulate") --------------------
+ * The same layers as above - DoubleConv / Down / Up / OutConv of src/Unet.py:8-82 - with every activation, pre-activation
+ * and activation gradient kept in HBM as bf16 (NHWC, `const void*` = unsigned short), statistics / parameters / parameter
+ * gradients fp32, fp32 accumulation on the MFMA.  Host mirror: mmft/unet16.py (one autograd node for UNet.forward,
+ * src/Unet.py:110-119).
+ *
+ * mmft_u16_pack_weights: all weights of a step re-packed by ONE launch into MFMA A-fragment order (bf16).  descs: device
+ * array of n records {const float* w; unsigned short* out; int rows, K, taps, mode, Rsrc, Ksrc} (mmft_u16_pack_desc_bytes
+ * each): mode 0 = w[(row * taps + t) * Ksrc + k] (Conv2d weight [Co][3][3][Ci], src/Unet.py:16,19; ConvTranspose2d matrix
+ * [(a,b,co)][ci], src/Unet.py:53), 1 = flipped taps / transposed channels (input gradient), 2 = transposed matrix. */
+int mmft_u16_pack_desc_bytes(void);
+int mmft_u16_pack_weights(const void* descs, int n, long long max_frag_lanes, int device, void* stream);
+/* Conv2d(k=3, padding=1, bias=False) (src/Unet.py:16,19), Ci, Co in {16,32,64,128} or the 3 -> 16 RGB layer (x fp32
+ * [N][H][W][3]); the input gradient is the same call on the gradient with the mode-1 pack.  stats != NULL: per tile
+ * [2][Co] = sum, sum of squares of the stored (rounded) outputs - the BatchNorm statistics of src/Unet.py:17,20.
+ * mmft_u16_conv_tiles: rows of `stats`. */
+int mmft_u16_conv_tiles(int N, int H, int W, int* per_image);
+int mmft_u16_conv3x3(const void* x, int rgb_f32, const void* wpk, void* y, float* stats, int N, int H, int W, int Ci, int Co,
+                     int device, void* stream);
+long long mmft_u16_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Ci, int Co);
+int mmft_u16_conv3x3_wgrad(const void* x, int rgb_f32, const void* dy, float* dw, int accumulate, int N, int H, int W, int Ci,
+                           int Co, float* workspace, long long workspace_bytes, int device, void* stream);
+/* BatchNorm2d in train mode, per-image statistics (src/Unet.py:17,20; one image per call in src/train.py:465) + ReLU
+ * (:18,21).  finalize: tile partials -> bnp[5][N][C] = mean, invstd, biased variance, scale, shift.  apply:
+ * a = relu(z * scale + shift) written with pixel pitch lda (a channel slice of the concatenation of src/Unet.py:67),
+ * pooled != NULL: the 2x2 pooling of src/Unet.py:33-36 in the same pass; running_mean != NULL: the N sequential momentum
+ * updates of the running statistics (one per image).  bwd: g -> dz, dgamma, dbeta. */
+int mmft_u16_bn_finalize(const float* stats, int tiles_per_image, int N, int C, long long pixels_per_image, float eps,
+                         const float* gamma, const float* beta, float* bnp, int device, void* stream);
+int mmft_u16_bn_apply(const void* z, const float* bnp, void* a, int lda, void* pooled, int N, int H, int W, int C, int pool_mode,
+                      float momentum, float* running_mean, float* running_var, int device, void* stream);
+long long mmft_u16_bn_bwd_workspace_bytes(int N, long long pixels_per_image, int C);
+int mmft_u16_bn_bwd(const void* g, const void* z, const float* bnp, void* dz, float* dgamma, float* dbeta, int accumulate, int N,
+                    long long pixels_per_image, int C, float* workspace, long long workspace_bytes, int device, void* stream);
+/* backward of the 2x2 pooling (src/Unet.py:33-36) fused with the add of the skip connection's gradient (src/Unet.py:67):
+ * g = gskip + route(gp) */
+int mmft_u16_pool_bwd(const void* a, int lda, const void* gskip, int ldg, const void* gp, void* g, int N, int H, int W, int C,
+                      int pool_mode, int device, void* stream);
+/* ConvTranspose2d(Ci, Ci / 2, kernel_size=2, stride=2) (src/Unet.py:53) into / out of a channel slice (pitch ldu) of the
+ * concatenation buffer; dw in the parameter's (a,b,co,ci) memory order */
+int mmft_u16_convt_fwd(const void* x, const void* wpk, const float* bias, void* u, int ldu, int N, int h, int w, int Ci, int device,
+                       void* stream);
+int mmft_u16_convt_dgrad(const void* g, int ldu, const void* wpk_t, void* dx, int N, int h, int w, int Ci, int device, void* stream);
+long long mmft_u16_convt_wgrad_workspace_bytes(int N, int h, int w, int Ci);
+int mmft_u16_convt_wgrad(const void* x, const void* g, int ldu, float* dw, float* db, int accumulate, int N, int h, int w, int Ci,
+                         float* workspace, long long workspace_bytes, int device, void* stream);
+/* OutConv (src/Unet.py:71-82) on a bf16 input of 16 channels; out / gout fp32 */
+int mmft_u16_outconv_fwd(const void* x, const float* w, const float* bias, float* out, int N, int H, int W, int mode, int device,
+                         void* stream);
+long long mmft_u16_outconv_bwd_workspace_bytes(int N, int H, int W);
+int mmft_u16_outconv_bwd(const void* x, const float* w, const float* bias, const float* gout, void* dx, float* dw, float* db,
+                         int accumulate, int N, int H, int W, int mode, float* workspace, long long workspace_bytes, int device,
+                         void* stream);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,8 @@ import torch
 import torch.nn as nn
 
 from mmft import cnn as C
+from mmft import lib as _lib
+from mmft import unet16 as _u16
 
 
 def _pool_mode(pooling):
@@ -159,6 +161,9 @@ class UNet(nn.Module):
             x = x.unsqueeze(0)
         per_sample = self.inc.per_sample_stats
         self._count_batches(x.shape[0] if per_sample else 1)
+        if _lib.get_math_mode() == 'bf16' and _u16.supported(self, x):
+            # bf16 math mode: the whole network as one autograd node on bf16-STORAGE kernels (mmft/unet16.py)
+            return _u16.unet_forward(self, x)
         x1 = self.inc(x)
         x2 = self.down1(x1)
         x3 = self.down2(x2)

@@ -301,6 +301,172 @@ __global__ void __launch_bounds__(512) level_fwd_bf16_kernel(LevelFwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Fused forward level kernel, SLOT-TABLE form.  Same arithmetic as level_fwd_bf16_kernel<16> - every row
+// bitwise equal - with the serial latencies of a tile's dependent chain cut:
+//   * `slots` (static, built on the host next to the CSR): per cell row of fan-in <= 4 the four (row of h to read, row of
+//     PRE to add or -1) pairs of its in-edges in edge order - ONE 32-byte load whose address is known at kernel entry
+//     replaces ic_ptr -> (ic_idx, ic_drv); an edge from an older net level reads PRE of a fixed hot row instead of a
+//     512-byte row it then ignores;
+//   * the read-modify-write operand h[v] of the second epilogue is requested at kernel entry, next to the first layer's
+//     weight fragments, instead of behind the second MFMA phase;
+//   * the net rows of level l - 1 are no longer separate workgroups (504 cell tiles + 504 net blocks on 512 workgroup
+//     slots = two rounds, the second one waiting for the first): workgroup b also writes net rows 16 b .. 16 b + 15,
+//     their loads issued ahead of the gather through `net_drv` (the single driver of every net, static).
+struct LevelSlotsArgs {
+  float* h;
+  const float* pre;
+  long long ld;
+  const int* slots;      // [N][8]: hrow[4], prow[4]; hrow < 0: no edge; prow < 0: the edge's value is h[hrow] itself
+  const int* net_drv;    // [N]: driver row of a net, < 0: none
+  int net_row0, n_net, cell_row0, n_cell;
+  float *A, *LSE;
+  const unsigned short *w1, *w2;
+  const float *b1, *b2;
+  float* hid_out;
+  long long ldhid;
+  int relu;
+  const unsigned char* active;
+  int cell_tiles;
+};
+
+__global__ void __launch_bounds__(512) level_fwd_slots_kernel(LevelSlotsArgs a) {
+  constexpr int BM = 16;
+  __shared__ __attribute__((aligned(16))) unsigned short xs[BM * L2_XS];
+  __shared__ __attribute__((aligned(16))) unsigned short hs[BM * L2_HS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x, gr = tid >> 5, gc = (tid & 31) * 4;              // gather / net item of this thread: (row, channel group)
+  const bool has_cell = b < a.cell_tiles;
+  const int m0 = b * BM;
+  // ---- requests whose addresses are known now
+  const int nrow = b * BM + gr, u = a.net_row0 + nrow;
+  const bool net_ok = nrow < a.n_net && (!a.active || a.active[u]);
+  int nd = -1;
+  f32x4 npre = {0.f, 0.f, 0.f, 0.f};
+  if (net_ok) {
+    nd = a.net_drv[u];
+    npre = *reinterpret_cast<const f32x4*>(a.pre + (long long)u * a.ld + gc);
+  }
+  const int v = a.cell_row0 + m0 + gr;
+  const bool live = has_cell && m0 + gr < a.n_cell && (!a.active || a.active[v]);
+  int hrow[4] = {-1, -1, -1, -1}, prow[4] = {-1, -1, -1, -1};
+  if (live) {
+    const int4 s0 = *reinterpret_cast<const int4*>(a.slots + (long long)v * 8);
+    const int4 s1 = *reinterpret_cast<const int4*>(a.slots + (long long)v * 8 + 4);
+    hrow[0] = s0.x; hrow[1] = s0.y; hrow[2] = s0.z; hrow[3] = s0.w;
+    prow[0] = s1.x; prow[1] = s1.y; prow[2] = s1.z; prow[3] = s1.w;
+  }
+  bf16x8 w1f[2][4], w2f[8];
+  // epilogue-2 operand of this lane: row m0 + r16, output features wave * 16 + 4 q ..
+  const int ev = a.cell_row0 + m0 + r16;
+  const bool elive = has_cell && m0 + r16 < a.n_cell && (!a.active || a.active[ev]);
+  f32x4 hold = {0.f, 0.f, 0.f, 0.f};
+  if (has_cell) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        w1f[j][ks] = *reinterpret_cast<const bf16x8*>(a.w1 + (long long)(wave * 32 + j * 16 + r16) * L2_K1 + ks * 32 + q * 8);
+    if (elive) hold = *reinterpret_cast<const f32x4*>(a.h + (long long)ev * a.ld + wave * 16 + q * 4);
+  }
+  // ---- net row of level l - 1: h[u] = act(PRE[u] + h[driver])   (mean over ONE in-edge = the driver's row itself)
+  if (net_ok) {
+    f32x4 hd = {0.f, 0.f, 0.f, 0.f};
+    if (nd >= 0) hd = *reinterpret_cast<const f32x4*>(a.h + (long long)nd * a.ld + gc);
+    *reinterpret_cast<f32x4*>(a.h + (long long)u * a.ld + gc) = fg_finish_net(hd, npre, a.relu);
+  }
+  if (!has_cell) return;
+  if (a.active) {
+    int any = 0;
+    if (tid < BM) any = (m0 + tid < a.n_cell && a.active[a.cell_row0 + m0 + tid]) ? 1 : 0;
+    if (!__syncthreads_or(any)) return;
+  }
+  // ---- gather of the thread's (row, channel group): the four slots requested together, consumed in edge order
+  {
+    f32x4 av = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      const int h0 = hrow[0] >= 0 ? hrow[0] : v;             // an empty row still issues (and drops) loads of valid rows
+      f32x4 xa[4], xp[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        xa[k] = *reinterpret_cast<const f32x4*>(a.h + (long long)(hrow[k] >= 0 ? hrow[k] : h0) * a.ld + gc);
+        xp[k] = *reinterpret_cast<const f32x4*>(a.pre + (long long)(prow[k] >= 0 ? prow[k] : a.net_row0) * a.ld + gc);
+      }
+      SoftAcc sa;
+      sa.init();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 x = prow[k] >= 0 ? fg_finish_net(xa[k], xp[k], a.relu) : xa[k];
+        SoftAcc nx = sa;
+        nx.add(x);
+        const bool ok = hrow[k] >= 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sa.mx[j] = ok ? nx.mx[j] : sa.mx[j];
+          sa.s[j] = ok ? nx.s[j] : sa.s[j];
+          sa.acc[j] = ok ? nx.acc[j] : sa.acc[j];
+        }
+      }
+      f32x4 lv = {0.f, 0.f, 0.f, 0.f};
+      if (hrow[0] >= 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          av[j] = sa.acc[j] / sa.s[j];
+          lv[j] = sa.mx[j] + logf(sa.s[j]);
+        }
+      }
+      *reinterpret_cast<f32x4*>(a.A + (long long)v * a.ld + gc) = av;
+      *reinterpret_cast<f32x4*>(a.LSE + (long long)v * a.ld + gc) = lv;
+    }
+    const unsigned lo = pack_bf16(av.x, av.y), hi = pack_bf16(av.z, av.w);
+    *reinterpret_cast<unsigned long long*>(xs + gr * L2_XS + gc) = ((unsigned long long)hi << 32) | lo;
+  }
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+    w2f[ks] = *reinterpret_cast<const bf16x8*>(a.w2 + (long long)(wave * 16 + r16) * L2_HD + ks * 32 + q * 8);
+  __syncthreads();
+  // ---- phase 1 / epilogue 1 / phase 2 / epilogue 2: as level_fwd_bf16_kernel<16>
+  f32x4 acc1[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) acc1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xs + r16 * L2_XS + ks * 32 + q * 8);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[j][ks], xf, acc1[j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int nn = wave * 32 + j * 16 + q * 4;
+    f32x4 hv = acc1[j];
+    if (a.b1) hv += *reinterpret_cast<const f32x4*>(a.b1 + nn);
+    hv.x = hv.x > 0.f ? hv.x : 0.f; hv.y = hv.y > 0.f ? hv.y : 0.f;
+    hv.z = hv.z > 0.f ? hv.z : 0.f; hv.w = hv.w > 0.f ? hv.w : 0.f;
+    const unsigned lo = pack_bf16(hv.x, hv.y), hi = pack_bf16(hv.z, hv.w);
+    *reinterpret_cast<unsigned long long*>(hs + r16 * L2_HS + nn) = ((unsigned long long)hi << 32) | lo;
+    if (a.hid_out && elive) *reinterpret_cast<f32x4*>(a.hid_out + (long long)ev * a.ldhid + nn) = hv;
+  }
+  __syncthreads();
+  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hs + r16 * L2_HS + ks * 32 + q * 8);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[ks], hf, acc2, 0, 0, 0);
+  }
+  if (elive) {
+    const int nn = wave * 16 + q * 4;
+    f32x4 o = acc2;
+    if (a.b2) o += *reinterpret_cast<const f32x4*>(a.b2 + nn);
+    o += hold;
+    if (a.relu) {
+      o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+      o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(a.h + (long long)ev * a.ld + nn) = o;
+  }
+}
+
 // dst[r][c] (bf16) = src[r][c], or with transpose dst[c][r] = src[r][c]   (R x C fp32, row stride ld)
 __global__ void __launch_bounds__(256) pack_bf16_kernel(const float* __restrict__ src, long long ld, int R, int C,
                                                         unsigned short* __restrict__ dst, int transpose) {
@@ -379,4 +545,26 @@ extern "C" int mmft_level_fwd_bf16(float* h, const float* pre, long long ld, int
   MMFT_LAUNCH("level_fwd_bf16_kernel", fl, alg_bytes > 0 ? (double)alg_bytes : 0.0, level_fwd_bf16_kernel<LV_BM>,
               dim3(tiles + net_blocks), dim3(512), (hipStream_t)stream, a);
   return check_launch("level_fwd_bf16");
+}
+
+extern "C" int mmft_level_fwd_slots(float* h, const float* pre, long long ld, int D, const int* slots, const int* net_driver,
+                                    int net_row0, int n_net, int cell_row0, int n_cell, float* A, float* LSE, const void* w1_bf16,
+                                    const float* b1, const void* w2_bf16, const float* b2, float* hid_out, long long ldhid, int relu,
+                                    const unsigned char* active, long long alg_bytes, int device, void* stream) {
+  MMFT_REQUIRE(D == L2_K1, "level_fwd_slots: D must be %d", L2_K1);
+  MMFT_REQUIRE(n_net >= 0 && n_cell >= 0 && net_row0 >= 0 && cell_row0 >= 0, "level_fwd_slots: negative row count / offset");
+  if (n_net + n_cell == 0) return MMFT_OK;
+  MMFT_REQUIRE(h && pre && slots && net_driver && (n_cell == 0 || (A && LSE && w1_bf16 && w2_bf16)), "level_fwd_slots: null pointer");
+  MMFT_REQUIRE(ld >= D && ld % 4 == 0 && aligned16(h) && aligned16(pre) && aligned16(slots) && (!A || aligned16(A)) &&
+                   (!LSE || aligned16(LSE)) && (!w1_bf16 || aligned16(w1_bf16)) && (!w2_bf16 || aligned16(w2_bf16)) &&
+                   (!b1 || aligned16(b1)) && (!b2 || aligned16(b2)) && (!hid_out || (aligned16(hid_out) && ldhid % 4 == 0)),
+               "level_fwd_slots: operands must be 16-byte aligned");
+  DeviceGuard dg(device);
+  const int tiles = cdiv(n_cell, 16), net_tiles = cdiv(n_net, 16);
+  LevelSlotsArgs a{h, pre, ld, slots, net_driver, net_row0, n_net, cell_row0, n_cell, A, LSE, (const unsigned short*)w1_bf16,
+                   (const unsigned short*)w2_bf16, b1, b2, hid_out, ldhid, relu, active, tiles};
+  const double fl = 2.0 * n_cell * ((double)L2_K1 * L2_HD + (double)L2_HD * L2_D2);
+  MMFT_LAUNCH("level_fwd_slots_kernel", fl, alg_bytes > 0 ? (double)alg_bytes : 0.0, level_fwd_slots_kernel,
+              dim3(tiles > net_tiles ? tiles : net_tiles), dim3(512), (hipStream_t)stream, a);
+  return check_launch("level_fwd_slots");
 }

@@ -210,8 +210,9 @@ class MaskedFcFn(torch.autograd.Function):
                 return t
             GP = _fc_cached('GP', (w, feat_map), _gp)
             if lib.PROF_ON:         # runs of the sampled paths: the static average per path (the ids live on the device)
+                # HBM side: every prefix row at most once (the two reads per run mostly hit L2 / MALL), the run lists, the output
                 R = T * m.num_runs / max(m.num_paths, 1)
-                lib.prof_hint(2.0 * R * Dout, R * (2 * Dout * 4 + 8) + T * (Dout * 4 + 12))
+                lib.prof_hint(2.0 * R * Dout, min(2.0 * R, float(m.B * P)) * Dout * 4 + R * 8 + T * (Dout * 4 + 12))
             lib.call('mmft_masked_fc_fwd_runs', m.run_ptr, m.run_start, m.run_len, pm.paths, pm.f_off, T, GP, b, out, Dout,
                      m.run_block, dev, st)
         else:
@@ -237,10 +238,12 @@ class MaskedFcFn(torch.autograd.Function):
                 pm.masks.run_block * Dout * 4 <= 65536 and pm.masks.run_block % (512 // groups) == 0:
             ws = lib.workspace(f.device, lib.query('mmft_masked_fc_bwd_runs_workspace_bytes', B, P, Dout))
             if lib.PROF_ON:
-                # boundary entries of the sampled paths (static average per path): one gout row each; per design the wT
-                # block is read and the dwT slab written once, f / df / the boundary pointers once per cell
+                # boundary entries of the sampled paths (static average per path): one gout row each (HBM side: each of the T
+                # rows at most once); per design the wT block is read and the dwT slab written once, f / df / the boundary
+                # pointers once per cell
                 E = g.shape[0] * pm.masks.bnd_code.numel() / max(pm.masks.num_paths, 1)
-                lib.prof_hint(E * Dout + 4.0 * B * P * Dout, E * (Dout * 4 + 4) + 2.0 * B * P * Dout * 4 + 12.0 * B * P)
+                lib.prof_hint(E * Dout + 4.0 * B * P * Dout,
+                              min(E, float(g.shape[0])) * Dout * 4 + E * 4 + 2.0 * B * P * Dout * 4 + 12.0 * B * P)
             lib.call('mmft_masked_fc_bwd_runs', pm.masks.bnd_ptr, pm.masks.bnd_code, pm.first, pm.next, g, f, wT, dwT, df,
                      B, P, Dout, pm.masks.run_block, ws, ws.numel() * 4, dev, st)
         else:

@@ -256,6 +256,34 @@ def level_fwd_bf16(h, pre, in_net, in_cell, net_range, cell_rows, A, LSE, w1p, b
              _edge_drivers(in_cell_driver, in_cell[1]), int(alg_bytes), dev, st)
 
 
+def level_fwd_slots(h, pre, slots, net_driver, net_range, cell_range, A, LSE, w1p, b1, w2p, b2, hid_out, relu=True, active=None,
+                    alg_bytes=0):
+    """Slot-table form of level_fwd_bf16 (mmft_level_fwd_slots): contiguous net / cell row ranges, fan-in <= 4."""
+    for t, nm in ((h, 'h'), (pre, 'pre'), (A, 'A'), (LSE, 'LSE')):
+        _rows2d(t, nm)
+        if t.shape != h.shape or t.stride(0) != h.stride(0):
+            raise ValueError(f'level_fwd_slots: {nm} must have the layout of h')
+    N = h.shape[0]
+    if h.shape[1] != 128:
+        raise ValueError('level_fwd_slots: D = 128 only')
+    for t, nm, shape in ((slots, 'slots', (N, 8)), (net_driver, 'net_driver', (N,))):
+        if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.int32 and tuple(t.shape) == shape and t.is_contiguous()):
+            raise ValueError(f'level_fwd_slots: {nm} must be a contiguous int32 CUDA tensor of shape {shape}')
+    nrow0, nn = net_range if net_range is not None else (0, 0)
+    crow0, nc = cell_range
+    if min(nrow0, nn, crow0, nc) < 0 or nrow0 + nn > N or crow0 + nc > N:
+        raise ValueError('level_fwd_slots: row range outside the graph')
+    for t, nm, shape in ((w1p, 'w1p', (256, 128)), (w2p, 'w2p', (128, 256))):
+        if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.bfloat16 and tuple(t.shape) == shape and t.is_contiguous()):
+            raise ValueError(f'level_fwd_slots: {nm} must be a contiguous bf16 CUDA tensor of shape {shape}')
+    _rows2d(hid_out, 'hid_out')
+    if hid_out.shape != (N, 256):
+        raise ValueError('level_fwd_slots: hid_out must be [N, 256]')
+    dev, st = lib.stream_args(h)
+    lib.call('mmft_level_fwd_slots', h, pre, h.stride(0), 128, slots, net_driver, nrow0, nn, crow0, nc, A, LSE, w1p, b1, w2p, b2,
+             hid_out, hid_out.stride(0), int(relu), _active(active, N), int(alg_bytes), dev, st)
+
+
 def mlp2_feat_fusable(fin, HD, D2):
     return 1 <= fin <= 64 and HD == 256 and D2 == 128
 

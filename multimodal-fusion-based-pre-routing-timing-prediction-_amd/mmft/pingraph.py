@@ -333,6 +333,43 @@ class PinGraph:
         self._lists_store(key, level_nodes, sched)
         return sched
 
+    def level_slots(self, level_nodes):
+        """Static tables of the slot-form level kernel (mmft_level_fwd_slots), or None when the schedule is not a folded one:
+        (slots int32[N][8], net_driver int32[N], per-level maximum cell fan-in).  slots[v] = hrow[0..3], prow[0..3] of v's
+        cell in-edges in edge order: an edge from a net u of the level right below v (the folded one) reads h[driver(u)] and
+        adds pre[u] (hrow = driver, prow = u), any other edge reads h[u] (prow = -1); unused slots are -1; a row with more
+        than four in-edges has hrow[0] = -2 (such levels keep the index-chasing kernels).  Cached per list objects."""
+        if self.fold_schedule(level_nodes) is None:
+            return None
+        key = ('slots',) + self._lists_key(level_nodes)
+        hit = self._lists_hit(key, level_nodes)
+        if hit is not None:
+            return hit[0]
+        N = self._n
+        lev = np.full(N, -1, dtype=np.int64)
+        for l, nodes in enumerate(level_nodes):
+            lev[np.asarray(nodes, dtype=np.int64)] = l
+        nptr, nidx = self._csr_host[('in', 'net')][0], self._csr_host[('in', 'net')][1]
+        cptr, cidx = self._csr_host[('in', 'cell')][0], self._csr_host[('in', 'cell')][1]
+        ndeg, cdeg = np.diff(nptr), np.diff(cptr)
+        net_drv = np.full(N, -1, dtype=np.int32)
+        one = ndeg == 1
+        net_drv[one] = nidx[nptr[:-1][one]]
+        slots = np.full((N, 8), -1, dtype=np.int32)
+        for k in range(4):
+            rows = np.nonzero(cdeg > k)[0]
+            if rows.size == 0:
+                break
+            u = cidx[cptr[rows] + k].astype(np.int64)
+            folded = (lev[u] == lev[rows] - 1) & (net_drv[u] >= 0)
+            slots[rows, k] = np.where(folded, net_drv[u], u)
+            slots[rows, 4 + k] = np.where(folded, u, -1)
+        slots[cdeg > 4, 0] = -2
+        max_in = [int(cdeg[np.asarray(nodes, dtype=np.int64)].max()) if len(nodes) else 0 for nodes in level_nodes]
+        out = (torch.from_numpy(slots).to(self.device), torch.from_numpy(net_drv).to(self.device), max_in)
+        self._lists_store(key, level_nodes, out)
+        return out
+
     # ------------------------------------------------------------------ construction helpers
     @staticmethod
     def from_synth(d, out_dim=None):

@@ -57,6 +57,7 @@ class SweepState:
         self.bwd_active = False
         self.complete = False               # level lists = a complete schedule of the graph (whole-sweep entry)
         self.fold = None                    # static facts for the folded level kernels (PinGraph.fold_schedule)
+        self.level_lists = None
         self.PRE = None
         self.attn = None                    # attention branch (flag_attn): dict(key, c12, alpha, dcp, o2i)
         self.wpack = None                   # bf16 math mode: fc_cell_neigh pre-packed as bf16 (W1, W2, W2^T, W1^T)
@@ -449,6 +450,7 @@ def level_forward(conv, graph, cur_nodes, targets, level_id):
 EDGE_DRIVERS = True                 # folded gather: per-edge driver table (3-deep load chain, four edges in flight)
 FEAT_MLP_NO_HIDDEN = True           # bf16 mode: fc_cell_self / fc_net_self as one kernel each way, hidden activations recomputed
 FUSE_LEVEL_FWD = True               # bf16 mode: folded gather + fused MLP of a level pair in one launch (mmft_level_fwd_bf16)
+LEVEL_SLOTS = True                  # ... in its slot-table form where the level allows it (mmft_level_fwd_slots: fan-in <= 4, ranges)
 FOLD_LEVELS = True                  # folded forward chain (one gather per (net, cell) level PAIR) when the graph allows it
 FUSED_FIRST_LAYER_GRADS = True      # mmft_mlp2_first_layer_grads for the *_self MLPs (False: dgrad GEMM + wgrad GEMM)
 
@@ -504,6 +506,8 @@ class SweepFn(torch.autograd.Function):
             # folded chain: one gather launch per (net level l - 1, cell level l) pair + the fused MLP of the cell level
             L = len(level_rows)
             drv = g.cell_edge_drivers() if EDGE_DRIVERS else None
+            slot_tabs = g.level_slots(st.level_lists) if (LEVEL_SLOTS and FUSE_LEVEL_FWD and st.wpack is not None
+                                                         and getattr(st, 'level_lists', None) is not None) else None
             for level_id in range(2, L + 1, 2):
                 net_l = level_id - 1
                 has_cell = level_id < L and level_rows[level_id].numel() > 0
@@ -514,7 +518,17 @@ class SweepFn(torch.autograd.Function):
                 crow = None
                 if has_cell:
                     crow = fold[level_id]['range'] or level_rows[level_id]
-                if has_cell and st.wpack is not None and fold[level_id]['heavy_in'] is None and FUSE_LEVEL_FWD:
+                fused = has_cell and st.wpack is not None and fold[level_id]['heavy_in'] is None and FUSE_LEVEL_FWD
+                level_bytes = (meta_n['bytes_mean'] if meta_n else 0) + (meta_c['bytes_softmax'] if meta_c else 0) + \
+                    (level_rows[level_id].numel() * (8 * st.D + 4 * st.Hd) if (meta_c and has_cell) else 0)
+                if fused and slot_tabs is not None and fold[level_id]['range'] is not None and slot_tabs[2][level_id] <= 4 and \
+                        (fold[net_l]['range'] is not None or not fold[net_l]['n']):
+                    # ... with the static slot table instead of the per-edge index chain, net rows inside the cell workgroups
+                    ops.level_fwd_slots(st.h, st.PRE, slot_tabs[0], slot_tabs[1], fold[net_l]['range'] or (0, 0), fold[level_id]['range'],
+                                        st.A, st.LSE, st.wpack[0], b1g, st.wpack[1], b2g, st.HN, relu=st.relu, active=st.active,
+                                        alg_bytes=level_bytes)
+                    continue
+                if fused:
                     # bf16 mode: gather + fc_cell_neigh of the pair in ONE launch
                     ops.level_fwd_bf16(st.h, st.PRE, in_net, in_cell, fold[net_l]['range'] or (0, 0), crow, st.A, st.LSE,
                                        st.wpack[0], b1g, st.wpack[1], b2g, st.HN, relu=st.relu, active=st.active, in_cell_driver=drv,
@@ -625,6 +639,7 @@ def _run_sweep(conv, graph, level_nodes, tix, target_order=None, targets_unique=
     st.active = active
     st.complete = graph.level_set_is_complete(level_nodes)
     st.fold = graph.fold_schedule(level_nodes) if (FOLD_LEVELS and st.complete and not getattr(conv, 'flag_attn', False)) else None
+    st.level_lists = level_nodes if st.fold is not None else None       # key of the static slot tables (PinGraph.level_slots)
     st.target_order, st.targets_unique = target_order, targets_unique
     level_rows = [graph.level_rows(l, nodes, 'nodes') for l, nodes in enumerate(level_nodes)]
     st.level_meta = [graph.level_meta(l, nodes, st.D) if not torch.is_tensor(nodes) else None

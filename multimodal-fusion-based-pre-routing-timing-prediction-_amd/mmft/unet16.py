@@ -1,0 +1,334 @@
+"""bf16-STORAGE path of the layout U-Net (bf16 math mode): UNet.forward (src/Unet.py:110-119) as ONE autograd node.
+
+Every activation, pre-activation and activation gradient lives in HBM as bf16 (BASELINE config B: "bf16 storage / fp32
+accumulate"); BatchNorm statistics, parameters, parameter gradients and Adam state stay fp32.  What the fp32 path does in
+~190 launches per step (cnn.py: one autograd Function per operator) runs here as
+
+    forward   per DoubleConv layer (src/Unet.py:8-25):  convolution (+ BatchNorm partial sums in its epilogue) -> finalize
+              -> apply (+ ReLU, + the 2x2 pooling of the following Down block, written straight into the skip half of the
+              Up block's concatenation buffer);  ConvTranspose2d writes the other half in place;  OutConv in one kernel
+    backward  per layer: BatchNorm backward (partial sums, finalize, apply) -> weight gradient -> input gradient; the
+              pooling backward adds the skip connection's gradient in the same pass (no autograd add kernels)
+
+with the 64 / 128-channel stages on the same tile-resident convolution kernels as the narrow ones (csrc/unet16_conv.hip)
+and all weights re-packed to MFMA fragment order by one launch per step.  Selected by Unet.UNet.forward when
+lib.get_math_mode() == 'bf16' and the input qualifies (`supported`); everything else takes the fp32 operators of cnn.py.
+"""
+import ctypes
+import math
+
+import torch
+from torch import nn
+
+from . import gradsink, lib, ops
+
+ENABLED = True          # False: UNet.forward keeps the per-operator fp32-storage path in bf16 mode as well (comparison runs)
+
+
+def supported(net, x):
+    """The fused path covers the reference's own configuration: UNet(pooling, bilinear=False) on an fp32 (N,3,H,W) batch
+    whose sides survive three 2x2 poolings and the OutConv kernel's 32-pixel row segments."""
+    if not ENABLED or net.bilinear or x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or not x.is_cuda:
+        return False
+    if x.shape[0] > 1 and not net.inc.per_sample_stats:
+        return False                    # batch statistics over several images: the fp32 operators handle that
+    H, W = x.shape[2], x.shape[3]
+    return H % 8 == 0 and W % 32 == 0 and H >= 8
+
+
+# (name of the DoubleConv, index of the conv inside it) in forward order; conv i (1-based) = CONVS[i - 1]
+def _layers(net):
+    dcs = [net.inc, net.down1.maxpool_conv[1], net.down2.maxpool_conv[1], net.down3.maxpool_conv[1],
+           net.up1.conv, net.up2.conv, net.up3.conv]
+    out = []
+    for dc in dcs:
+        s = dc.double_conv
+        out.append((s[0], s[1]))
+        out.append((s[3], s[4]))
+    return out                                    # 14 x (Conv2d, BatchNorm2d)
+
+
+class _PackDesc(ctypes.Structure):
+    _fields_ = [('w', ctypes.c_void_p), ('out', ctypes.c_void_p), ('rows', ctypes.c_int), ('K', ctypes.c_int), ('taps', ctypes.c_int),
+                ('mode', ctypes.c_int), ('Rsrc', ctypes.c_int), ('Ksrc', ctypes.c_int)]
+
+
+def _pad16(n):
+    return (n + 15) // 16 * 16
+
+
+def pack_table(entries, device):
+    """entries: (name, fp32 source tensor, rows, K, taps, mode, Rsrc, Ksrc) - see mmft_u16_pack_weights in include/mmft.h.
+    Returns (bf16 buffer, device descriptor table, {name: element offset}, widest entry in fragment lanes)."""
+    assert lib.query('mmft_u16_pack_desc_bytes') == ctypes.sizeof(_PackDesc)
+    total = sum(rows * K * taps for _, _, rows, K, taps, _, _, _ in entries)
+    buf = torch.empty(total, dtype=torch.bfloat16, device=device)
+    descs = (_PackDesc * len(entries))()
+    offs, off, lanes = {}, 0, 0
+    for j, (name, p, rows, K, taps, mode, Rsrc, Ksrc) in enumerate(entries):
+        descs[j] = _PackDesc(p.data_ptr(), buf.data_ptr() + off * 2, rows, K, taps, mode, Rsrc, Ksrc)
+        offs[name] = off
+        off += rows * K * taps
+        lanes = max(lanes, rows * K * taps // 4)
+    table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(device)
+    return buf, table, offs, lanes
+
+
+def pack_run(buf, table, n, lanes):
+    dev, st = lib.stream_args(buf)
+    lib.call('mmft_u16_pack_weights', table, n, lanes, dev, st)
+
+
+def conv_pack_entries(name, weight, backward=False):
+    """Pack entries of one Conv2d(k=3) weight stored channels_last: forward fragments, or the flipped / transposed ones of
+    the input gradient."""
+    Co, Ci = weight.shape[0], weight.shape[1]
+    if not ops.is_nhwc(weight):
+        raise RuntimeError('unet16: Conv2d weights must be stored channels_last ([Co][3][3][Ci] memory)')
+    if backward:
+        return (name, weight, Ci, Co, 9, 1, Ci, Co)
+    return (name, weight, Co, _pad16(Ci), 9, 0, Co, Ci)
+
+
+def convt_pack_entries(name, weight, backward=False):
+    Ci, Co = weight.shape[0], weight.shape[1]
+    if not weight.permute(2, 3, 1, 0).is_contiguous():
+        raise RuntimeError('unet16: ConvTranspose2d weights must be stored in (a,b,co,ci) memory order')
+    if backward:
+        return (name, weight, Ci, 4 * Co, 1, 2, Ci, 4 * Co)
+    return (name, weight, 4 * Co, Ci, 1, 0, 4 * Co, Ci)
+
+
+class _Packs:
+    """Packed bf16 weights of one UNet: forward and flipped (input-gradient) fragments of the 14 convolutions, forward and
+    transposed fragments of the 3 transposed convolutions.  The descriptor table is rebuilt when a parameter's storage
+    moved (FlatAdam re-homes the parameters once); the pack itself is ONE launch per forward."""
+
+    def __init__(self, net, device):
+        self.key = None
+        self.device = device
+
+    def _build(self, net):
+        entries = []
+        for i, (cv, _) in enumerate(_layers(net)):
+            entries.append(conv_pack_entries('f%d' % i, cv.weight))
+            if i > 0:                                      # the first layer's input needs no gradient
+                entries.append(conv_pack_entries('b%d' % i, cv.weight, backward=True))
+        for k, up in enumerate([net.up1.up, net.up2.up, net.up3.up]):
+            entries.append(convt_pack_entries('tf%d' % k, up.weight))
+            entries.append(convt_pack_entries('tb%d' % k, up.weight, backward=True))
+        self.buf, self.descs, self.off, self.lanes = pack_table(entries, self.device)
+        self.n = len(entries)
+
+    def refresh(self, net):
+        key = tuple(p.data_ptr() for p in net.parameters())
+        if key != self.key:
+            self._build(net)
+            self.key = key
+        pack_run(self.buf, self.descs, self.n, self.lanes)
+
+    def ptr(self, name):
+        return self.buf.data_ptr() + self.off[name] * 2
+
+
+def _arena(sizes, dtype, device, align=128):
+    """One allocation carved into named flat tensors (offsets rounded up to `align` elements)."""
+    off, table = 0, {}
+    for name, n in sizes:
+        table[name] = (off, n)
+        off += (n + align - 1) // align * align
+    buf = torch.empty(max(off, 1), dtype=dtype, device=device)
+    return buf, {k: buf[o:o + n] for k, (o, n) in table.items()}
+
+
+class _Sink:
+    """Where a parameter gradient goes: straight into FlatAdam's flat gradient buffer when the parameter has a sink and
+    its memory order is the kernels' output order, else a fresh tensor returned through autograd."""
+
+    def __init__(self, param, mem_shape, to_logical):
+        self.rec = gradsink.of(param)
+        self.to_logical = to_logical
+        view = None
+        if self.rec is not None:
+            mem, _ = gradsink._memory_order(self.rec[0])
+            if mem is not None and mem.numel() == math.prod(mem_shape):
+                view = mem.reshape(mem_shape)
+        self.direct = view is not None
+        if self.direct:
+            self.out, self.accumulate = view, not gradsink.fresh(self.rec)
+        else:
+            self.out, self.accumulate = torch.empty(mem_shape, dtype=torch.float32, device=param.device), False
+
+    def done(self):
+        """Call once the producing kernel has been issued; returns what backward() must return for the parameter."""
+        if self.direct:
+            if not self.accumulate:
+                gradsink.taken(self.rec)
+            return None
+        return self.to_logical(self.out)
+
+
+def _geometry(N, H, W):
+    lv = [(H >> k, W >> k) for k in range(4)]
+    P = [N * h * w for h, w in lv]
+    return lv, P
+
+
+# conv i (1-based): (Ci, Co, level, input buffer name)
+_CONV = {1: (3, 16, 0, 'x'), 2: (16, 16, 0, 'a1'), 3: (16, 32, 1, 'p1'), 4: (32, 32, 1, 'a3'), 5: (32, 64, 2, 'p2'),
+         6: (64, 64, 2, 'a5'), 7: (64, 128, 3, 'p3'), 8: (128, 128, 3, 'a7'), 9: (128, 64, 2, 'cat1'), 10: (64, 64, 2, 'a9'),
+         11: (64, 32, 1, 'cat2'), 12: (32, 32, 1, 'a11'), 13: (32, 16, 0, 'cat3'), 14: (16, 16, 0, 'a13')}
+# where conv i's activation is written: (buffer, pixel pitch, pooled buffer or None)
+_ACT = {1: ('a1', 16, None), 2: ('cat3', 32, 'p1'), 3: ('a3', 32, None), 4: ('cat2', 64, 'p2'), 5: ('a5', 64, None),
+        6: ('cat1', 128, 'p3'), 7: ('a7', 128, None), 8: ('a8', 128, None), 9: ('a9', 64, None), 10: ('a10', 64, None),
+        11: ('a11', 32, None), 12: ('a12', 32, None), 13: ('a13', 16, None), 14: ('a14', 16, None)}
+# transposed convolutions: k -> (Ci, input activation, concatenation buffer, channel offset of its slice, level of the INPUT)
+_UP = {0: (128, 'a8', 'cat1', 64, 3), 1: (64, 'a10', 'cat2', 32, 2), 2: (32, 'a12', 'cat3', 16, 1)}
+
+
+class UNet16Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, net, pool_mode, *params):
+        N, _, H, W = x.shape
+        dev, st = lib.stream_args(x)
+        lv, P = _geometry(N, H, W)
+        convs = _layers(net)
+        ups = [net.up1.up, net.up2.up, net.up3.up]
+        packs = net.__dict__.get('_u16_packs')
+        if packs is None or packs.device != x.device:
+            packs = net.__dict__['_u16_packs'] = _Packs(net, x.device)
+        packs.refresh(net)
+        xn = ops.to_nhwc(x)                                 # fp32 [N][H][W][3]
+        sizes = [('z%d' % i, P[_CONV[i][2]] * _CONV[i][1]) for i in range(1, 15)]
+        sizes += [('a1', P[0] * 16), ('cat3', P[0] * 32), ('p1', P[1] * 16), ('a3', P[1] * 32), ('cat2', P[1] * 64), ('p2', P[2] * 32),
+                  ('a5', P[2] * 64), ('cat1', P[2] * 128), ('p3', P[3] * 64), ('a7', P[3] * 128), ('a8', P[3] * 128), ('a9', P[2] * 64),
+                  ('a10', P[2] * 64), ('a11', P[1] * 32), ('a12', P[1] * 32), ('a13', P[0] * 16), ('a14', P[0] * 16)]
+        abuf, T = _arena(sizes, torch.bfloat16, x.device)
+        per_img = ctypes.c_int(0)
+        tiles0 = lib.load().mmft_u16_conv_tiles(N, lv[0][0], lv[0][1], ctypes.byref(per_img))
+        fbuf, F = _arena([('stats', tiles0 * 2 * 128)] + [('bnp%d' % i, 5 * N * _CONV[i][1]) for i in range(1, 15)],
+                         torch.float32, x.device, align=4)
+        momentum_ok = all(bn.momentum is not None and bn.affine and bn.track_running_stats for _, bn in convs)
+        if not momentum_ok:
+            raise NotImplementedError('unet16: BatchNorm2d without momentum / affine / running statistics is not on the reference path')
+        src = {'x': xn}
+        for i in range(1, 15):
+            Ci, Co, l, inp = _CONV[i]
+            h, w = lv[l]
+            cv, bn = convs[i - 1]
+            xin = src[inp] if inp == 'x' else T[inp]
+            tiles = lib.load().mmft_u16_conv_tiles(N, h, w, ctypes.byref(per_img))
+            lib.call('mmft_u16_conv3x3', xin, 1 if inp == 'x' else 0, packs.ptr('f%d' % (i - 1)), T['z%d' % i], F['stats'], N, h, w,
+                     Ci, Co, dev, st)
+            lib.call('mmft_u16_bn_finalize', F['stats'], per_img.value, N, Co, h * w, float(bn.eps), bn.weight.detach(), bn.bias.detach(),
+                     F['bnp%d' % i], dev, st)
+            abuf_name, lda, pooled = _ACT[i]
+            lib.call('mmft_u16_bn_apply', T['z%d' % i], F['bnp%d' % i], T[abuf_name], lda, T[pooled] if pooled else None, N, h, w, Co,
+                     pool_mode, float(bn.momentum), bn.running_mean, bn.running_var, dev, st)
+            for k, (uCi, uin, cat, coff, ul) in _UP.items():
+                if uin == abuf_name:                        # the Up block's transposed convolution follows this layer
+                    up = ups[k]
+                    uh, uw = lv[ul]
+                    lib.call('mmft_u16_convt_fwd', T[uin], packs.ptr('tf%d' % k), up.bias.detach() if up.bias is not None else None,
+                             T[cat].data_ptr() + coff * 2, 2 * (uCi // 2), N, uh, uw, uCi, dev, st)
+        oc = net.outc.conv[0]
+        out = torch.empty((N, 1, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        lib.call('mmft_u16_outconv_fwd', T['a14'], oc.weight.detach(), oc.bias.detach() if oc.bias is not None else None, out, N, H, W,
+                 pool_mode, dev, st)
+        ctx.net, ctx.pool_mode, ctx.geom = net, pool_mode, (N, H, W)
+        ctx.keep = (xn, abuf, T, fbuf, F, packs)
+        ctx.nparams = len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        net, pool_mode = ctx.net, ctx.pool_mode
+        N, H, W = ctx.geom
+        xn, _abuf, T, _fbuf, F, packs = ctx.keep
+        g = gout if gout.is_contiguous() else gout.contiguous()
+        dev, st = lib.stream_args(g)
+        lv, P = _geometry(N, H, W)
+        convs = _layers(net)
+        ups = [net.up1.up, net.up2.up, net.up3.up]
+        sizes = [('g%d' % i, P[_CONV[i][2]] * _CONV[i][1]) for i in range(1, 15)] + [('dz%d' % i, P[_CONV[i][2]] * _CONV[i][1]) for i in range(1, 15)]
+        sizes += [('gcat3', P[0] * 32), ('gcat2', P[1] * 64), ('gcat1', P[2] * 128), ('gp1', P[1] * 16), ('gp2', P[2] * 32), ('gp3', P[3] * 64)]
+        _gbuf, G = _arena(sizes, torch.bfloat16, g.device)
+        q = lambda name, *a: lib.query(name, *a)
+        ws_bytes = max([q('mmft_u16_outconv_bwd_workspace_bytes', N, H, W)] +
+                       [q('mmft_u16_bn_bwd_workspace_bytes', N, lv[_CONV[i][2]][0] * lv[_CONV[i][2]][1], _CONV[i][1]) for i in range(1, 15)] +
+                       [q('mmft_u16_conv3x3_wgrad_workspace_bytes', N, lv[_CONV[i][2]][0], lv[_CONV[i][2]][1], _CONV[i][0], _CONV[i][1])
+                        for i in range(1, 15)] +
+                       [q('mmft_u16_convt_wgrad_workspace_bytes', N, lv[u[4]][0], lv[u[4]][1], u[0]) for u in _UP.values()])
+        ws = lib.workspace(g.device, ws_bytes)
+        grads = {}
+
+        oc = net.outc.conv[0]
+        s_w = _Sink(oc.weight, (16,), lambda t: t.reshape(oc.weight.shape))
+        s_b = _Sink(oc.bias, (1,), lambda t: t.reshape(oc.bias.shape)) if oc.bias is not None else None
+        if s_b is not None and s_b.accumulate != s_w.accumulate:
+            raise RuntimeError('unet16: OutConv weight / bias sinks out of step')
+        lib.call('mmft_u16_outconv_bwd', T['a14'], oc.weight.detach(), oc.bias.detach() if oc.bias is not None else None, g, G['g14'],
+                 s_w.out, s_b.out if s_b is not None else None, int(s_w.accumulate), N, H, W, pool_mode, ws, ws.numel() * 4, dev, st)
+        grads[id(oc.weight)] = s_w.done()
+        if s_b is not None:
+            grads[id(oc.bias)] = s_b.done()
+
+        def conv_backward(i):
+            Ci, Co, l, inp = _CONV[i]
+            h, w = lv[l]
+            cv, bn = convs[i - 1]
+            s_g, s_bt = _Sink(bn.weight, (Co,), lambda t: t), _Sink(bn.bias, (Co,), lambda t: t)
+            if s_g.accumulate != s_bt.accumulate:
+                raise RuntimeError('unet16: BatchNorm weight / bias sinks out of step')
+            lib.call('mmft_u16_bn_bwd', G['g%d' % i], T['z%d' % i], F['bnp%d' % i], G['dz%d' % i], s_g.out, s_bt.out, int(s_g.accumulate),
+                     N, h * w, Co, ws, ws.numel() * 4, dev, st)
+            grads[id(bn.weight)], grads[id(bn.bias)] = s_g.done(), s_bt.done()
+            s_cw = _Sink(cv.weight, (Co, 3, 3, Ci), lambda t: t.permute(0, 3, 1, 2))
+            xin = xn if inp == 'x' else T[inp]
+            lib.call('mmft_u16_conv3x3_wgrad', xin, 1 if inp == 'x' else 0, G['dz%d' % i], s_cw.out, int(s_cw.accumulate), N, h, w, Ci, Co,
+                     ws, ws.numel() * 4, dev, st)
+            grads[id(cv.weight)] = s_cw.done()
+            if inp == 'x':
+                return
+            tgt = {'cat1': 'gcat1', 'cat2': 'gcat2', 'cat3': 'gcat3', 'p1': 'gp1', 'p2': 'gp2', 'p3': 'gp3'}.get(inp)
+            if tgt is None:
+                tgt = 'g%d' % (i - 1)                      # plain activation of the previous convolution
+            lib.call('mmft_u16_conv3x3', G['dz%d' % i], 0, packs.ptr('b%d' % (i - 1)), G[tgt], None, N, h, w, Co, Ci, dev, st)
+
+        def up_backward(k, g_target):
+            uCi, uin, cat, coff, ul = _UP[k]
+            up = ups[k]
+            uh, uw = lv[ul]
+            Co = uCi // 2
+            gslice = G['g' + cat].data_ptr() + coff * 2
+            s_uw = _Sink(up.weight, (4 * Co, uCi), lambda t: t.reshape(2, 2, Co, uCi).permute(3, 2, 0, 1))
+            s_ub = _Sink(up.bias, (Co,), lambda t: t) if up.bias is not None else None
+            if s_ub is not None and s_ub.accumulate != s_uw.accumulate:
+                raise RuntimeError('unet16: ConvTranspose2d weight / bias sinks out of step')
+            lib.call('mmft_u16_convt_wgrad', T[uin], gslice, 2 * Co, s_uw.out, s_ub.out if s_ub is not None else None, int(s_uw.accumulate),
+                     N, uh, uw, uCi, ws, ws.numel() * 4, dev, st)
+            grads[id(up.weight)] = s_uw.done()
+            if s_ub is not None:
+                grads[id(up.bias)] = s_ub.done()
+            lib.call('mmft_u16_convt_dgrad', gslice, 2 * Co, packs.ptr('tb%d' % k), G[g_target], N, uh, uw, uCi, dev, st)
+
+        def pool_backward(cat, C, l, gp, g_target):
+            h, w = lv[l]
+            lib.call('mmft_u16_pool_bwd', T[cat], 2 * C, G['g' + cat], 2 * C, G[gp], G[g_target], N, h, w, C, pool_mode, dev, st)
+
+        conv_backward(14); conv_backward(13); up_backward(2, 'g12')
+        conv_backward(12); conv_backward(11); up_backward(1, 'g10')
+        conv_backward(10); conv_backward(9); up_backward(0, 'g8')
+        conv_backward(8); conv_backward(7); pool_backward('cat1', 64, 2, 'gp3', 'g6')
+        conv_backward(6); conv_backward(5); pool_backward('cat2', 32, 1, 'gp2', 'g4')
+        conv_backward(4); conv_backward(3); pool_backward('cat3', 16, 0, 'gp1', 'g2')
+        conv_backward(2); conv_backward(1)
+        plist = list(net.parameters())
+        return (None, None, None) + tuple(grads.get(id(p)) for p in plist)
+
+
+def unet_forward(net, x):
+    """UNet.forward (src/Unet.py:110-119) on the bf16-storage kernels; x: fp32 (N,3,H,W)."""
+    pooling = net.down1.maxpool_conv[0]
+    pool_mode = ops.POOL_MAX if isinstance(pooling, nn.MaxPool2d) else ops.POOL_AVG
+    return UNet16Fn.apply(x, net, pool_mode, *list(net.parameters()))

@@ -179,8 +179,10 @@ def _cos(a, b):
 
 
 def test_config_a_step_vs_oracle_bf16(dev):
-    """One full config-A train step (U-Net, 32-level sweep, fusion head, MSE, backward) in bf16 mode against the fp64
-    oracle: predictions within 5e-2 of their scale, loss within 10 %, gradient directions within cos >= 0.98 (GNN, fusion head) / >= 0.85 (U-Net, mean >= 0.97)."""
+    """One full config-A train step (U-Net on its bf16-STORAGE path, 32-level sweep, fusion head, MSE, backward) in bf16 mode
+    against the fp64 oracle: predictions within 5e-2 of their scale, loss within 10 %, gradient directions within
+    cos >= 0.98 (GNN, fusion head) / >= 0.85 per U-Net tensor with the mean over all tensors >= 0.95 (activations and
+    activation gradients rounded to bf16 at each of the 14 BatchNorm layers; 0.967 measured, 0.977 with fp32 storage)."""
     from mmft.synth import config_design
     from mmft.train import build_models, TrainStep
     from mmft.fusion import mse_loss
@@ -211,7 +213,7 @@ def test_config_a_step_vs_oracle_bf16(dev):
     head = [c for k, c in cos.items() if k.startswith(('fcn', 'mlp_', 'gnn.'))]
     assert min(head) > 0.98, sorted(cos.items(), key=lambda kv: kv[1])[:5]
     # the U-Net's first layers sit behind 14 BatchNorm + ReLU + max-pool stages whose decisions a rounding can flip
-    assert min(cos.values()) > 0.85 and np.mean(list(cos.values())) > 0.97, sorted(cos.items(), key=lambda kv: kv[1])[:5]
+    assert min(cos.values()) > 0.85 and np.mean(list(cos.values())) > 0.95, sorted(cos.items(), key=lambda kv: kv[1])[:5]
     # and the mode really changes the arithmetic: fp32 mode is >100x closer
     with lib.math_mode('f32'):
         hats32, _, _ = ts.forward([path_ids])
@@ -243,9 +245,10 @@ def test_training_in_bf16_tracks_fp32(dev):
 
 
 def test_fused_level_kernel_equals_two_kernel_form(dev):
-    """bf16 mode: mmft_level_fwd_bf16 (folded gather + fc_cell_neigh of a level pair in one launch) against the two-kernel
-    form (mmft_pair_fwd_gather, then mmft_mlp2_rows_bf16): same instruction sequences per row -> bitwise equal embeddings,
-    and the same gradients from the reverse sweep."""
+    """bf16 mode: the three forms of the forward level chain - two kernels (mmft_pair_fwd_gather, then mmft_mlp2_rows_bf16),
+    the fused kernel (mmft_level_fwd_bf16) and its slot-table form (mmft_level_fwd_slots: static per-row edge slots, net rows
+    inside the cell workgroups, early read-modify-write operand) - run the same instruction sequences per row: bitwise
+    equal embeddings, saved state and gradients."""
     from mmft import sweep as S
     from mmft.synth import synth_design
     from mmft.train import build_models, DesignBatch
@@ -253,26 +256,35 @@ def test_fused_level_kernel_equals_two_kernel_form(dev):
     b = DesignBatch(designs, dev)
     pmodel, _ = build_models(map_size=designs[0].map_size, device=dev, seed=8)
     ends = b.select([np.arange(0, d.num_paths, 3) for d in designs])[0]
-    res = []
-    for fuse in (True, False):
-        S.FUSE_LEVEL_FWD = fuse
+    res, names = [], []
+    for fuse, slots in ((True, True), (True, False), (False, False)):
+        S.FUSE_LEVEL_FWD, S.LEVEL_SLOTS = fuse, slots
         try:
             g = b.graph
             g.ndata['h'] = torch.zeros((b.N, 128), dtype=torch.float32, device=dev)
             for p in pmodel.gnn.parameters():
                 p.grad = None
+            lib.prof_reset()
+            lib.prof_enable(True)
             out = S.sweep_forward_all(pmodel.gnn, g, b.level_nodes, ends)
+            torch.cuda.synchronize()
+            lib.prof_enable(False)
+            names.append({r['name'] for r in lib.prof_report()})
             st = g._sweep
             assert st.wpack is not None and st.fold is not None
             (out * out).sum().backward()
-            res.append((out.detach().clone(), g.ndata['h'].clone(), st.A.clone(), st.HN.clone(),
+            res.append((out.detach().clone(), g.ndata['h'].clone(), st.A.clone(), st.HN.clone(), st.LSE.clone(),
                         {k: p.grad.clone() for k, p in pmodel.gnn.named_parameters() if p.grad is not None}))
         finally:
-            S.FUSE_LEVEL_FWD = True
-    for x, y in zip(res[0][:4], res[1][:4]):
-        assert torch.equal(x, y)
-    for k in res[1][4]:
-        assert torch.equal(res[0][4][k], res[1][4][k]), k
+            S.FUSE_LEVEL_FWD, S.LEVEL_SLOTS = True, True
+    assert 'level_fwd_slots_kernel' in names[0] and 'level_fwd_bf16_kernel' not in names[0]
+    assert 'level_fwd_bf16_kernel' in names[1] and 'level_fwd_slots_kernel' not in names[1]
+    assert 'pair_fwd_gather_kernel' in names[2] and 'level_fwd_bf16_kernel' not in names[2]
+    for other in (res[0], res[1]):
+        for x, y in zip(other[:5], res[2][:5]):
+            assert torch.equal(x, y)
+        for k in res[2][5]:
+            assert torch.equal(other[5][k], res[2][5][k]), k
 
 
 @pytest.mark.parametrize('fin,n,row0', [(36, 1000, 7), (2, 4099, 0), (36, 70000, 128), (5, 33, 3)])
