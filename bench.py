@@ -255,6 +255,7 @@ def main():
                          '(the 1e-4 parity mode the GPU tests run in)')
     ap.add_argument('--cpu-steps', type=int, default=10)
     ap.add_argument('--no-drift', action='store_true', help='bf16: skip the fp32 replay of the schedule (MAE drift)')
+    ap.add_argument('--no-dropin', action='store_true', help='skip the extra timings of the per-level drop-in API')
     ap.add_argument('--cone', action='store_true',
                     help='fan-in-cone pruning inside the step (device-side mask per step; pays when --batch-paths is small)')
     args = ap.parse_args()
@@ -432,6 +433,31 @@ def main():
         log(f"fp32 replay ({ts2.optim.step_count} steps): held-out slack MAE {f32_ref['endpoint_slack_mae']:.4f} "
             f"(bf16 run: {heldout_mae['endpoint_slack_mae']:.4f})")
 
+    # the per-level drop-in API (src/train.py:490-511 as written: model(...) once per level) on the same workload, OUTSIDE the
+    # timed region: with the MaskedPathMap handle in place of the dense map, and with the reference's literal
+    # dense `path_mask.to_dense() * feat_map`
+    dropin = {}
+    if rank == 0 and world == 1 and args.mode == 'sweep' and not args.no_dropin:
+        for key, dense in (('dropin_ms_per_step', False), ('dropin_dense_ms_per_step', True)):
+            try:
+                pm3, cnn3 = build_models(map_size=designs[0].map_size, device=dev, seed=9294)
+                ts3 = TrainStep(pm3, cnn3, designs, dev, world_size=1, mode='dropin', dense_path_map=dense)
+                sched = HISTORY[:7]
+                for ids in sched[:2]:
+                    ts3.step(ids)
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                for ids in sched[2:]:
+                    ts3.step(ids)
+                torch.cuda.synchronize()
+                dropin[key] = (time.perf_counter() - t3) / max(len(sched) - 2, 1) * 1e3
+                log(f'{key}: {dropin[key]:.2f} ms ({len(sched) - 2} steps)')
+                del ts3, pm3, cnn3
+                torch.cuda.empty_cache()
+            except Exception as e:                       # noqa: BLE001 - an extra measurement must not cost the bench line
+                dropin[key] = None
+                log(f'{key}: failed ({type(e).__name__}: {e})')
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log('timing the CPU oracle (bounded sample)')
@@ -480,6 +506,7 @@ def main():
             'roofline': roofline,
             'cpu_baseline': cpu,
         }
+        out.update(dropin)
         if cpu is not None:
             out['speedup_vs_cpu_baseline'] = value / cpu['value']
         print(json.dumps(out))

@@ -475,7 +475,8 @@ int mmft_outconv_bwd(const float* x, const float* w, const float* bias, const fl
  * mmft_u16_pack_weights: all weights of a step re-packed by ONE launch into MFMA A-fragment order (bf16).  descs: device
  * array of n records {const float* w; unsigned short* out; int rows, K, taps, mode, Rsrc, Ksrc} (mmft_u16_pack_desc_bytes
  * each): mode 0 = w[(row * taps + t) * Ksrc + k] (Conv2d weight [Co][3][3][Ci], src/Unet.py:16,19; ConvTranspose2d matrix
- * [(a,b,co)][ci], src/Unet.py:53), 1 = flipped taps / transposed channels (input gradient), 2 = transposed matrix. */
+ * [(a,b,co)][ci], src/Unet.py:53), 1 = flipped taps / transposed channels (input gradient), 2 = transposed matrix; + 4 = fragments of the 16x16x32
+ * MFMA (8 consecutive k per lane) - what mmft_u16_conv3x3 expects when its reduction channel count is >= 32. */
 int mmft_u16_pack_desc_bytes(void);
 int mmft_u16_pack_weights(const void* descs, int n, long long max_frag_lanes, int device, void* stream);
 /* Conv2d(k=3, padding=1, bias=False) (src/Unet.py:16,19), Ci, Co in {16,32,64,128} or the 3 -> 16 RGB layer (x fp32

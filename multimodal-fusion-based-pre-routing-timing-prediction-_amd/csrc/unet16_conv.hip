@@ -11,6 +11,7 @@
 //     values (the BatchNorm statistics of src/Unet.py:17,20 are taken of exactly the tensor that is stored): one
 //     [2][CO] row per tile, combined in fp64 in a fixed order by mmft_u16_bn_finalize - no extra pass over the tensor;
 //   * tiles are 4 x 64 pixels (W >= 64) or 8 x 32; partial tiles are masked, so any H, W works.
+#include <type_traits>
 #include "unet16.h"
 
 namespace mmft {
@@ -24,17 +25,21 @@ struct U16PackDesc {
   int mode;          // 0: w[(row * taps + t) * Ksrc + k]            (forward conv weight [Co][3][3][Ci]; matrix [rows][K])
                      // 1: w[(k * taps + (taps - 1 - t)) * Rsrc + row] (input gradient: flipped taps, transposed channels)
                      // 2: w[k * Rsrc + row]                          (transposed matrix, taps = 1)
+                     // + 4: fragments of v_mfma_f32_16x16x32_bf16 (8 consecutive k per lane, K a multiple of 32)
   int Rsrc, Ksrc;    // real extents of the source (Ksrc = 3 for the RGB layer: padded with zeros up to K = 16)
 };
 
-// out[((mb * taps + t) * KB + kb) * 256 + lane * 4 + j] = A_t[16 mb + r][16 kb + 4 q + j],  lane = 16 q + r
+// out[((mb * taps + t) * KB + kb) * 64 * KW + lane * KW + j] = A_t[16 mb + r][4 KW kb + KW q + j],  lane = 16 q + r;
+// KW = 4 (v_mfma_f32_16x16x16_bf16 fragments) or 8 (16x16x32).  One thread per (fragment, lane, group of 4 k).
 __global__ void __launch_bounds__(256) u16_pack_kernel(const U16PackDesc* __restrict__ descs) {
   const U16PackDesc d = descs[blockIdx.y];
-  const int KB = d.K / 16, MB = d.rows / 16;
-  const long long frags = (long long)MB * d.taps * KB * 64;          // one thread per (fragment, lane)
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < frags; e += (long long)gridDim.x * 256) {
-    const int lane = (int)(e & 63);
-    long long f = e >> 6;
+  const int mode = d.mode & 3, KW = (d.mode & 4) ? 8 : 4, G = KW / 4;
+  const int KB = d.K / (4 * KW), MB = d.rows / 16;
+  const long long items = (long long)MB * d.taps * KB * 64 * G;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < items; e += (long long)gridDim.x * 256) {
+    const int g = (int)(e % G);
+    const int lane = (int)((e / G) & 63);
+    long long f = e / (64 * G);
     const int kb = (int)(f % KB);
     f /= KB;
     const int t = (int)(f % d.taps), mb = (int)(f / d.taps);
@@ -43,11 +48,11 @@ __global__ void __launch_bounds__(256) u16_pack_kernel(const U16PackDesc* __rest
     float v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int k = kb * 16 + 4 * q + j;
+      const int k = kb * 4 * KW + KW * q + 4 * g + j;
       float x = 0.f;
       if (row < d.Rsrc && k < d.Ksrc) {
-        if (d.mode == 0) x = d.w[((long long)row * d.taps + t) * d.Ksrc + k];
-        else if (d.mode == 1) x = d.w[((long long)k * d.taps + (d.taps - 1 - t)) * d.Rsrc + row];
+        if (mode == 0) x = d.w[((long long)row * d.taps + t) * d.Ksrc + k];
+        else if (mode == 1) x = d.w[((long long)k * d.taps + (d.taps - 1 - t)) * d.Rsrc + row];
         else x = d.w[(long long)k * d.Rsrc + row];
       }
       v[j] = x;
@@ -56,19 +61,25 @@ __global__ void __launch_bounds__(256) u16_pack_kernel(const U16PackDesc* __rest
   }
 }
 
+typedef __bf16 u16_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short u16_s16x8 __attribute__((ext_vector_type(8)));
+
 // ------------------------------------------------------------------------------------------------ forward / input gradient
 struct U16ConvArgs {
   const void* x;       // bf16 [N][H][W][CI]  (RGB: fp32 [N][H][W][3])
-  const u16* wpk;      // packed weights of the layer (all CO): [(CO / 16)][9][(CI / 16)][64][4]
+  const u16* wpk;      // packed weights of the layer (all CO): [(CO / 16)][9][(CI / KC)][64][KC / 4], KC = 32 (CI >= 32) or 16
   u16* y;              // bf16 [N][H][W][CO]
   float* stats;        // [tiles][2][CO] or null
   int N, H, W, CO;
   int tiles_x, tiles_y, tiles;
 };
 
+// Input channels >= 32: the 32-channel chunk is ONE v_mfma_f32_16x16x32_bf16 per tap (8 consecutive channels per lane = one
+// ds_read_b128, weights packed in the 16x16x32 fragment order); the pixel pitch CI + 16 keeps those reads conflict-free.
 template <int CI, int TH, int TW>
 struct U16ConvCfg {
-  static constexpr int XR = TH + 2, XC = TW + 2, PIX = CI + 8;
+  static constexpr bool K32 = CI >= 32;
+  static constexpr int XR = TH + 2, XC = TW + 2, PIX = CI + (K32 ? 16 : 8);
   static constexpr int XS_BYTES = XR * XC * PIX * 2;
   static constexpr int RED_BYTES = 4 * 2 * 32 * 4;
   static constexpr int LDS_BYTES = XS_BYTES + RED_BYTES;
@@ -77,8 +88,9 @@ struct U16ConvCfg {
 template <int CI, int COB, int TH, int TW, bool RGB>
 __global__ void __launch_bounds__(256) u16_conv3x3_kernel(U16ConvArgs a) {
   using C = U16ConvCfg<CI, TH, TW>;
-  constexpr int XR = C::XR, XC = C::XC, PIX = C::PIX, MB = COB / 16, CBT = CI / 16;
-  constexpr int KC = CI >= 32 ? 32 : 16, KCB = KC / 16, NCH = CI / KC;
+  constexpr int XR = C::XR, XC = C::XC, PIX = C::PIX, MB = COB / 16;
+  constexpr bool K32 = C::K32;
+  constexpr int KC = K32 ? 32 : 16, NCH = CI / KC;
   constexpr int STEPS = TH * TW / 16, SPR = TW / 16, SPW = STEPS / 4;
   static_assert(TW % 16 == 0 && CI % 16 == 0 && COB % 16 == 0 && STEPS % 4 == 0 && (!RGB || CI == 16), "granularity");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -89,15 +101,15 @@ __global__ void __launch_bounds__(256) u16_conv3x3_kernel(U16ConvArgs a) {
   const int mb0 = blockIdx.y * MB, co0 = mb0 * 16;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
-  s16x4 wf[9][KCB][MB];
+  // fragments of chunk ch: [(mb0 + m)][t][ch][lane][KC / 4 elements]
+  typedef typename std::conditional<K32, u16_bf16x8, s16x4>::type wfrag_t;
+  wfrag_t wf[9][MB];
   auto load_weights = [&](int ch) {
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int c = 0; c < KCB; ++c)
-#pragma unroll
-        for (int m = 0; m < MB; ++m)
-          wf[t][c][m] = *reinterpret_cast<const s16x4*>(a.wpk + ((((long long)(mb0 + m) * 9 + t) * CBT + ch * KCB + c) * 64 + lane) * 4);
+      for (int m = 0; m < MB; ++m)
+        wf[t][m] = *reinterpret_cast<const wfrag_t*>(a.wpk + ((((long long)(mb0 + m) * 9 + t) * NCH + ch) * 64 + lane) * (KC / 4));
   };
   if constexpr (NCH == 1) load_weights(0);
 
@@ -170,12 +182,18 @@ __global__ void __launch_bounds__(256) u16_conv3x3_kernel(U16ConvArgs a) {
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx)
+          {
+            const u16* xp = xs + ((row + ky) * XC + c0 + r + kx) * PIX + ch * KC + (KC / 4) * q;
+            if constexpr (K32) {
+              const u16_bf16x8 xf = *reinterpret_cast<const u16_bf16x8*>(xp);
 #pragma unroll
-            for (int c = 0; c < KCB; ++c) {
-              const s16x4 xf = *reinterpret_cast<const s16x4*>(xs + ((row + ky) * XC + c0 + r + kx) * PIX + ch * KC + c * 16 + 4 * q);
+              for (int m = 0; m < MB; ++m) acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ky * 3 + kx][m], xf, acc[s][m], 0, 0, 0);
+            } else {
+              const s16x4 xf = *reinterpret_cast<const s16x4*>(xp);
 #pragma unroll
-              for (int m = 0; m < MB; ++m) acc[s][m] = mfma_bf16_k16(wf[ky * 3 + kx][c][m], xf, acc[s][m]);
+              for (int m = 0; m < MB; ++m) acc[s][m] = mfma_bf16_k16(wf[ky * 3 + kx][m], xf, acc[s][m]);
             }
+          }
       }
     }
     // acc[s][m] at lane (pixel r, q) = output channels co0 + 16 m + 4 q .. + 3 of pixel (y0 + row, x0 + c0 + r)
@@ -269,8 +287,6 @@ __device__ __forceinline__ s16x4 lds_tr_read(const u16* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
 }
 
-typedef __bf16 u16_bf16x8 __attribute__((ext_vector_type(8)));
-typedef short u16_s16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ u16_bf16x8 join8(s16x4 lo, s16x4 hi) {
   u16_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(u16_bf16x8, v);

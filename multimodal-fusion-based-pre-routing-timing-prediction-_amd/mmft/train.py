@@ -169,13 +169,18 @@ class DesignBatch:
 
 class TrainStep:
     def __init__(self, pmodel, cnn, designs, device, lr=1e-3, weight_decay=0.0, fused_optimizer=True, world_size=1,
-                 mode='sweep', overlap=True, with_optimizer=True, task='reg', cone=False):
+                 mode='sweep', overlap=True, with_optimizer=True, task='reg', cone=False, dense_path_map=False):
         """mode='dropin': per-level model() calls exactly as src/train.py:490-511;
         mode='sweep': PathModel.forward_sweep, same arithmetic with level-invariant work hoisted.
         task='reg': MSE on the arrival time (nlabels = 1); task='cls': CrossEntropy on ndata['label'] with a
         nlabels-wide head (src/train.py:32,513-522; src/options.py:32,49)."""
         assert mode in ('dropin', 'sweep') and task in ('reg', 'cls')
         self.mode, self.task = mode, task
+        # dense_path_map (drop-in mode): the reference's literal per-level map, th.index_select(path_masks, 0, paths).to_dense()
+        # * feat_map (src/train.py:500-501: sparse COO masks with int64 values, promoted by the multiply), instead of the
+        # MaskedPathMap handle - what an UNMODIFIED caller loop passes; kept for measuring that form (bench.py)
+        self.dense_path_map = bool(dense_path_map) and mode == 'dropin'
+        self._sp_masks = None
         # cone=True (sweep mode): the level kernels skip every node outside the fan-in cone of the step's endpoints
         # (device-side mask per step; pays when few endpoints of a large design are sampled, see sweep_forward_all)
         self.cone = bool(cone) and mode == 'sweep'
@@ -246,7 +251,11 @@ class TrainStep:
             k = int(counts[level_id])
             targets = ends_d[pos:pos + k]
             path_map = None
-            if k and feat is not None:
+            if k and feat is not None and self.dense_path_map:
+                rows = paths_d[pos:pos + k].long()
+                path_mask = torch.index_select(self._sparse_masks(), 0, rows).to_dense()              # src/train.py:500
+                path_map = path_mask * (feat[foff_d[pos:pos + k].long() // b.P] if b.B > 1 else feat)  # src/train.py:501
+            elif k and feat is not None:
                 # per-level rows; the per-row feature-map offsets come from the packed selection (no lookup launch per
                 # level), the link lists are derived only if a per-level backward asks for them
                 path_map = MaskedPathMap(b.masks, paths_d[pos:pos + k], feat, foff_d[pos:pos + k] if b.B > 1 else None)
@@ -255,6 +264,17 @@ class TrainStep:
             if cur is not None:
                 hats.append(cur)
         return torch.cat(hats, 0), ends_d, ends_h
+
+    def _sparse_masks(self):
+        """path_masks as the reference stores them: sparse COO (num_paths, P) with int64 ones
+        (src/verilog_parser_asap7.py:1353-1355,1368), on the device."""
+        if self._sp_masks is None:
+            m = self.batch.masks
+            ip, cols = torch.from_numpy(m.host_indptr), torch.from_numpy(m.host_cols)
+            rows = torch.repeat_interleave(torch.arange(m.num_paths), ip[1:] - ip[:-1])
+            self._sp_masks = torch.sparse_coo_tensor(torch.stack([rows, cols]), torch.ones(cols.numel(), dtype=torch.int64),
+                                                     (m.num_paths, m.P)).coalesce().to(self.device)
+        return self._sp_masks
 
     def loss(self, hats, ends_d):
         """src/train.py:513-522: CrossEntropy(label_hats, labels) for task 'cls', MSE(label_hats, arrival_time) for 'reg'."""

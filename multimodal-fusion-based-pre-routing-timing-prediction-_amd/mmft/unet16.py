@@ -85,9 +85,10 @@ def conv_pack_entries(name, weight, backward=False):
     Co, Ci = weight.shape[0], weight.shape[1]
     if not ops.is_nhwc(weight):
         raise RuntimeError('unet16: Conv2d weights must be stored channels_last ([Co][3][3][Ci] memory)')
+    # reduction channels >= 32: fragments of the 16x16x32 MFMA (mode + 4), as mmft_u16_conv3x3 reads them
     if backward:
-        return (name, weight, Ci, Co, 9, 1, Ci, Co)
-    return (name, weight, Co, _pad16(Ci), 9, 0, Co, Ci)
+        return (name, weight, Ci, Co, 9, 1 + (4 if Co >= 32 else 0), Ci, Co)
+    return (name, weight, Co, _pad16(Ci), 9, 0 + (4 if Ci >= 32 else 0), Co, Ci)
 
 
 def convt_pack_entries(name, weight, backward=False):

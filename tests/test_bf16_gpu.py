@@ -328,8 +328,8 @@ def test_feature_mlp_without_hidden_tensor(dev, fin, n, row0, representable):
 def test_full_size_config_b_in_bf16_mode(dev):
     """the configuration bench.py times - config B at full size (8 x 65 536 nodes, 64 levels, 256 x 256
     tiles, 1350 endpoints per design) in bf16 math mode - under test: two independent runs of two optimizer steps end
-    bitwise equal, the replayed HIP graph follows the eager step, every parameter stays finite, the fused level kernel and
-    the tile convolutions are the kernels that ran, and the first step's predictions are within the stated 5e-2 (of the
+    bitwise equal, the replayed HIP graph follows the eager step, every parameter stays finite, the slot-table level kernel and
+    the bf16-storage U-Net convolutions are the kernels that ran, and the first step's predictions are within the stated 5e-2 (of the
     predictions' scale) of the fp32 run of the same step."""
     from mmft.synth import synth_design
     from mmft.train import build_models, TrainStep, GraphedTrainStep
@@ -359,8 +359,8 @@ def test_full_size_config_b_in_bf16_mode(dev):
 
     (a, names), (b, _), (g, _) = run('eager', 'bf16', profile=True), run('eager', 'bf16'), run('graph', 'bf16')
     # the kernels BENCH times are the ones this test ran
-    assert any(n.startswith('level_fwd_bf16_kernel') for n in names), sorted(names)
-    assert any(n.startswith('conv3x3_tile') for n in names) and any(n.startswith('conv3x3_wgrad_narrow') for n in names), sorted(names)
+    assert any(n.startswith('level_fwd_slots_kernel') for n in names), sorted(names)
+    assert any(n.startswith('u16_conv3x3_kernel') for n in names) and any(n.startswith('u16_conv3x3_wgrad_kernel') for n in names), sorted(names)
     assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])               # bitwise run to run
     assert abs(g[0] - a[0]) < 1e-4 * abs(a[0]) and rel_err(g[1], a[1]) < 1e-4                 # graph replay = eager
     assert bool(torch.isfinite(a[2]).all()) and bool(torch.isfinite(a[1]).all())
