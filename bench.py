@@ -296,7 +296,8 @@ def main():
     pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=9294)
     pm_state = {k: v.detach().cpu().clone() for k, v in pmodel.state_dict().items()}
     pc_state = {k: v.detach().cpu().clone() for k, v in cnn.state_dict().items()}
-    ts = TrainStep(pmodel, cnn, designs, dev, world_size=world, mode=args.mode, overlap=not args.no_overlap, cone=args.cone)
+    ts = TrainStep(pmodel, cnn, designs, dev, world_size=world, mode=args.mode, overlap=not args.no_overlap, cone=args.cone,
+                   keep_grads=False)
     rng = np.random.default_rng(1234 + rank)
     log('resident on device; warm-up')
     stepper, graphed = ts, False
@@ -419,7 +420,7 @@ def main():
         pm2, cnn2 = build_models(map_size=designs[0].map_size, device=dev, seed=9294)
         pm2.load_state_dict(pm_state)
         cnn2.load_state_dict(pc_state)
-        ts2 = TrainStep(pm2, cnn2, designs, dev, world_size=1, mode=args.mode, overlap=not args.no_overlap)
+        ts2 = TrainStep(pm2, cnn2, designs, dev, world_size=1, mode=args.mode, overlap=not args.no_overlap, keep_grads=False)
         gs2 = GraphedTrainStep(ts2, HISTORY[0], pieces={'auto': None, 'one': False, 'five': True}[args.graph_pieces])
         torch.cuda.synchronize()
         t_f32 = time.perf_counter()

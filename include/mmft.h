@@ -183,6 +183,11 @@ int mmft_seg_mean_add_act_fwd(float* h, long long ldh, const int* in_indptr, con
                               int device, void* stream);
 /* out[i] (+)= sum over the CSR segment of rows[i] of src[u]  (deterministic segmented row sum; with
  * accumulate != 0 the result is added to out[rows[i]] in place) */
+/* out[v] (+)= sum of the rows e of src with sorted_keys[e] == v, v < R; sorted_keys ascending (the gradient of
+ * mlp_alpha's level table gathered per endpoint in level order, src/model.py:280): segments found by binary search, rows
+ * added in a fixed order (bitwise reproducible). */
+int mmft_seg_sum_sorted(const float* src, long long lds, const int* sorted_keys, int nsrc, int R, int D, float* out, long long ldo,
+                        int accumulate, int device, void* stream);
 int mmft_seg_sum_fwd(const float* src, long long lds, const int* indptr, const int* indices,
                      const int* rows, int n, int D, float* out, long long ldo, int accumulate,
                      int device, void* stream);
@@ -365,7 +370,7 @@ int mmft_masked_fc_fwd_runs(const int* run_ptr, const int* run_start, const int*
  * (per-design slabs summed in fixed order) and df.  Dout / 4 must be a power of two <= 64, S * Dout * 4 <= 64 KB. */
 long long mmft_masked_fc_bwd_runs_workspace_bytes(int B, int P, int Dout);
 int mmft_masked_fc_bwd_runs(const int* bnd_ptr, const int* bnd_code, const int* first, const int* next, const float* gout,
-                            const float* f, const float* wT, float* dwT, float* df, int B, int P, int Dout, int S,
+                            long long ldg, const float* f, const float* wT, float* dwT, float* df, int B, int P, int Dout, int S,
                             float* workspace, long long workspace_bytes, int device, void* stream);
 /* Backward of the masked projection as a deterministic GATHER over the transposed masks (no atomics):
  * csc_indptr[B*P+1] / csc_paths[nnz] list, for every map cell (b, p), the path ids whose mask covers it
@@ -376,12 +381,16 @@ int mmft_masked_fc_bwd_runs(const int* bnd_ptr, const int* bnd_code, const int* 
  *   df[b][p]  = sum_c wT[p][c] * S[c]
  * For B > 1 the designs run in parallel block columns; workspace >= B*P*Dout*4 bytes holds their dwT slabs. */
 int mmft_masked_fc_bwd(const int* csc_indptr, const int* csc_paths, const int* first, const int* next,
-                       const float* gout, const float* f, const float* wT, float* dwT, float* df,
+                       const float* gout, long long ldg, const float* f, const float* wT, float* dwT, float* df,
                        int B, int P, int Dout, float* workspace, long long workspace_bytes,
                        int device, void* stream);
 /* loss = mean((pred-target)^2); grad[i] = 2*(pred[i]-target[i])/n   (single workgroup, n <= 2^24) */
 int mmft_mse_fwd_bwd(const float* pred, const float* target, int n, float* loss, float* grad,
                      int device, void* stream);
+/* the same with target[i] = table[idx[i] * ld]: the labels are (N, 1) node tensors indexed by the endpoints
+ * (arrival_time[target_list], src/train.py:519-522) */
+int mmft_mse_gather_fwd_bwd(const float* pred, const float* table, long long ld, const int* idx, int n, float* loss, float* grad,
+                            int device, void* stream);
 /* nn.CrossEntropyLoss() (mean) of the classification task (--task cls, nlabels classes; src/train.py:32,516-518) over
  * logits [n][C] and int64 labels: loss[0] = mean_t (logsumexp z_t - z_t[y_t]), grad[t][c] = (softmax - onehot) / n (grad may
  * be NULL).  eval_out (optional fp64[6]) = n, sum of losses, tp, fp, tn, fn with predicted class = argmax (first maximum)
@@ -414,9 +423,10 @@ int mmft_adam_step_dev(float* p, const float* g, float* m, float* v, long long n
 /* same, with the optimizer's step counter kept in DEVICE memory: state[0] = steps taken so far (advanced by the
  * launch), state[1] = 0 (scratch ticket).  Both bias corrections are derived in the kernel from state[0] + 1, so the
  * host uploads nothing per step and the launch can be captured in a HIP graph and replayed any number of times, with
- * the host running ahead of the device.  state is two int32 words, zeroed by the caller before the first step. */
-int mmft_adam_step_counted(float* p, const float* g, float* m, float* v, long long n, int* state, float lr, float beta1,
-                           float beta2, float eps, float weight_decay, float gscale, int device, void* stream);
+ * the host running ahead of the device.  state is two int32 words, zeroed by the caller before the first step.
+ * zero_grad != 0: g is zeroed by the same pass (optimizer.zero_grad() of src/train.py:552 without a fill launch). */
+int mmft_adam_step_counted(float* p, float* g, float* m, float* v, long long n, int* state, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, float gscale, int zero_grad, int device, void* stream);
 
 /* ---- design preprocessing: the graph-side steps the reference runs on networkx in Python ---- */
 /* Longest-path levels from the primary inputs `pis` (src/verilog_parser_asap7.py:1452-1517, cal_topo_level: frontier
@@ -466,6 +476,30 @@ int mmft_outconv_bwd(const float* x, const float* w, const float* bias, const fl
                      int accumulate, int Nimg, int H, int W, int Ci, int mode, float* workspace, long long workspace_bytes,
                      int device, void* stream);
 
+/* Predictions of ONE per-level call of PathModel.forward (src/model.py:269-292; the loop of src/train.py:490-511) in one entry
+ * point: out[t] = mlp_fuse([h[targets[t]] | fcn(masked path map of path t) | mlp_alpha(level)]) - gather, masked projection
+ * (run form over the prefix table GP of mmft_masked_fc_prefix), level embedding, Linear(Dh + Dc + Da, H1) - ReLU -
+ * Linear(H1, nout).  No state is kept for a backward pass. */
+long long mmft_head_level_workspace_bytes(int T, int Dh, int Dc, int Da, int H1);
+int mmft_head_level_fwd(const float* h, long long ldh, const int* targets, int T, int Dh, const int* run_ptr, const int* run_start,
+                        const int* run_len, const int* paths, const int* f_off, const float* GP, const float* fcn_bias, int Dc,
+                        int S, const float* alpha_row, int Da, const float* w1, const float* b1, int H1, const float* w2,
+                        const float* b2, int nout, float* workspace, long long workspace_bytes, float* out, int device, void* stream);
+
+/* out[t] = [a[t] | b[t] | c[t]] (row-wise concatenation of up to three blocks, c may be NULL): torch.cat((h_gnn, h_cnn,
+ * h_global), 1) of PathModel.forward (src/model.py:285-290) */
+int mmft_concat_cols(const float* a, long long lda, int Da, const float* b, long long ldb, int Db, const float* c, long long ldc,
+                     int Dc, float* out, long long ldo, int T, int device, void* stream);
+
+/* MMFT_MATH_BF16: dw [out][in] (+)= g^T x over `rows` rows and db [out] (+)= column sums of g (db may be NULL) for the two
+ * weight gradients of fc_cell_neigh (Linear(128, 256) / Linear(256, 128) over every cell node of the batch,
+ * src/model.py:48-51): (out, in) in {(128, 256), (256, 128)}, g [rows][ldg], x [rows][ldx] fp32 (rounded to bf16 at
+ * staging, fp32 accumulation); the row-major operands are transposed by the LDS hardware on the way to the MFMA. */
+int mmft_rows_outer_supported(int out, int in);
+long long mmft_rows_outer_workspace_bytes(long long rows, int out, int in);
+int mmft_rows_outer_bf16(const float* g, long long ldg, const float* x, long long ldx, float* dw, float* db, long long rows, int out,
+                         int in, int accumulate, float* workspace, long long workspace_bytes, int device, void* stream);
+
 /* ---- bf16-STORAGE layout U-Net (bf16 math mode; BASELINE config B "bf16 storage / fp32 accumulate") --------------------
  * The same layers as above - DoubleConv / Down / Up / OutConv of src/Unet.py:8-82 - with every activation, pre-activation
  * and activation gradient kept in HBM as bf16 (NHWC, `const void*` = unsigned short), statistics / parameters / parameter
@@ -478,7 +512,8 @@ int mmft_outconv_bwd(const float* x, const float* w, const float* bias, const fl
  * [(a,b,co)][ci], src/Unet.py:53), 1 = flipped taps / transposed channels (input gradient), 2 = transposed matrix; + 4 = fragments of the 16x16x32
  * MFMA (8 consecutive k per lane) - what mmft_u16_conv3x3 expects when its reduction channel count is >= 32. */
 int mmft_u16_pack_desc_bytes(void);
-int mmft_u16_pack_weights(const void* descs, int n, long long max_frag_lanes, int device, void* stream);
+int mmft_u16_pack_weights(const void* descs, int n, long long max_frag_lanes, long long* counters, int ncounters, long long inc,
+                          int device, void* stream);
 /* Conv2d(k=3, padding=1, bias=False) (src/Unet.py:16,19), Ci, Co in {16,32,64,128} or the 3 -> 16 RGB layer (x fp32
  * [N][H][W][3]); the input gradient is the same call on the gradient with the mode-1 pack.  stats != NULL: per tile
  * [2][Co] = sum, sum of squares of the stored (rounded) outputs - the BatchNorm statistics of src/Unet.py:17,20.

@@ -136,9 +136,9 @@ class UNet(nn.Module):
             if isinstance(m, DoubleConv):
                 m.count_batches = False
 
-    def _count_batches(self, n):
-        """num_batches_tracked += n for all 14 BatchNorm layers with ONE launch: the counters are kept as views of one
-        int64 vector (rebuilt whenever .to()/load replaced the buffer objects)."""
+    def _batch_counters(self):
+        """The 14 num_batches_tracked counters as ONE int64 vector (the buffers are views of it; rebuilt whenever .to() /
+        load replaced the buffer objects)."""
         bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
         views = self.__dict__.get('_nbt_views')
         if views is None or len(views) != len(bns) or any(b.num_batches_tracked is not v for b, v in zip(bns, views)):
@@ -147,7 +147,11 @@ class UNet(nn.Module):
             for b, v in zip(bns, views):
                 b._buffers['num_batches_tracked'] = v
             self.__dict__['_nbt_flat'], self.__dict__['_nbt_views'] = flat, views
-        self.__dict__['_nbt_flat'] += n
+        return self.__dict__['_nbt_flat']
+
+    def _count_batches(self, n):
+        """num_batches_tracked += n for all 14 BatchNorm layers with ONE launch."""
+        self._batch_counters().add_(n)
 
     def set_per_sample_stats(self, flag=True):
         """BatchNorm statistics per image instead of per batch (used when several designs are batched)."""
@@ -160,10 +164,11 @@ class UNet(nn.Module):
         if x.dim() == 3:                       # train() feeds (C,H,W), validate()/test() (1,C,H,W): SURVEY D3
             x = x.unsqueeze(0)
         per_sample = self.inc.per_sample_stats
-        self._count_batches(x.shape[0] if per_sample else 1)
         if _lib.get_math_mode() == 'bf16' and _u16.supported(self, x):
-            # bf16 math mode: the whole network as one autograd node on bf16-STORAGE kernels (mmft/unet16.py)
+            # bf16 math mode: the whole network as one autograd node on bf16-STORAGE kernels (mmft/unet16.py); the batch
+            # counters ride in its first launch
             return _u16.unet_forward(self, x)
+        self._count_batches(x.shape[0] if per_sample else 1)
         x1 = self.inc(x)
         x2 = self.down1(x1)
         x3 = self.down2(x2)

@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) masked_fc_fwd_runs_kernel(const int* __re
                                                                  const int* __restrict__ foff, int T,
                                                                  const float* __restrict__ GP,
                                                                  const float* __restrict__ bias, float* __restrict__ out,
-                                                                 int Dout, int S) {
+                                                                 int Dout, int S, long long ldo) {
   __shared__ f32x4 part[256];
   const int groups = Dout >> 2;
   const int J = 256 / groups;
@@ -137,8 +137,15 @@ __global__ void __launch_bounds__(256) masked_fc_fwd_runs_kernel(const int* __re
   if (threadIdx.x < groups) {
     f32x4 sum = bias ? *reinterpret_cast<const f32x4*>(bias + threadIdx.x * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     for (int jj = 0; jj < J; ++jj) sum += part[jj * groups + threadIdx.x];
-    *reinterpret_cast<f32x4*>(out + (long long)t * Dout + threadIdx.x * 4) = sum;
+    *reinterpret_cast<f32x4*>(out + (long long)t * ldo + threadIdx.x * 4) = sum;
   }
+}
+
+// out[t][0 .. D) = row[0 .. D) for every t (the level embedding of mlp_alpha, the same for all endpoints of a level)
+__global__ void __launch_bounds__(256) bcast_row_kernel(const float* __restrict__ row, int D, float* __restrict__ out, long long ldo, int T) {
+  const long long total = (long long)T * D;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+    out[(i / D) * ldo + i % D] = row[i % D];
 }
 
 // ---- backward of the run form --------------------------------------------------------------------------------
@@ -152,7 +159,7 @@ constexpr int MFB_THREADS = 512;      // 16 entry lanes x 32 channel groups at D
 template <int GROUPS>
 __global__ void __launch_bounds__(MFB_THREADS) masked_fc_bwd_runs_kernel(const int* __restrict__ bptr, const int* __restrict__ bcode,
                                                                  const int* __restrict__ first, const int* __restrict__ next,
-                                                                 const float* __restrict__ gout, const float* __restrict__ f,
+                                                                 const float* __restrict__ gout, long long ldg, const float* __restrict__ f,
                                                                  const float* __restrict__ wT, float* __restrict__ dwT,
                                                                  float* __restrict__ df, int P, int S) {
   constexpr int Dout = GROUPS * 4, J = MFB_THREADS / GROUPS;
@@ -163,7 +170,7 @@ __global__ void __launch_bounds__(MFB_THREADS) masked_fc_bwd_runs_kernel(const i
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   auto rowsum = [&](int t) {                        // duplicates of a path in the batch: rare, summed in batch order
     f32x4 sum = z;
-    for (; t >= 0; t = next[t]) sum += *reinterpret_cast<const f32x4*>(gout + (long long)t * Dout + c4 * 4);
+    for (; t >= 0; t = next[t]) sum += *reinterpret_cast<const f32x4*>(gout + (long long)t * ldg + c4 * 4);
     return sum;
   };
   const int cpl = S / J;
@@ -174,10 +181,10 @@ __global__ void __launch_bounds__(MFB_THREADS) masked_fc_bwd_runs_kernel(const i
       int k0 = bcode[e], k1 = bcode[e + 1], k2 = bcode[e + 2], k3 = bcode[e + 3];
       int t0 = first[k0 >= 0 ? k0 : -k0 - 1], t1 = first[k1 >= 0 ? k1 : -k1 - 1];
       int t2 = first[k2 >= 0 ? k2 : -k2 - 1], t3 = first[k3 >= 0 ? k3 : -k3 - 1];
-      f32x4 r0 = t0 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t0 * Dout + c4 * 4) : z;
-      f32x4 r1 = t1 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t1 * Dout + c4 * 4) : z;
-      f32x4 r2 = t2 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t2 * Dout + c4 * 4) : z;
-      f32x4 r3 = t3 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t3 * Dout + c4 * 4) : z;
+      f32x4 r0 = t0 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t0 * ldg + c4 * 4) : z;
+      f32x4 r1 = t1 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t1 * ldg + c4 * 4) : z;
+      f32x4 r2 = t2 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t2 * ldg + c4 * 4) : z;
+      f32x4 r3 = t3 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t3 * ldg + c4 * 4) : z;
       if (t0 >= 0) r0 += rowsum(next[t0]);
       if (t1 >= 0) r1 += rowsum(next[t1]);
       if (t2 >= 0) r2 += rowsum(next[t2]);
@@ -213,7 +220,7 @@ __global__ void __launch_bounds__(MFB_THREADS) masked_fc_bwd_runs_kernel(const i
 // cell (b,p) through the transposed masks (fixed order -> bitwise reproducible); df by an LDS reduction
 __global__ void __launch_bounds__(256) masked_fc_bwd_kernel(const int* __restrict__ cptr, const int* __restrict__ cpaths,
                                                             const int* __restrict__ first, const int* __restrict__ next,
-                                                            const float* __restrict__ gout, const float* __restrict__ f,
+                                                            const float* __restrict__ gout, long long ldg, const float* __restrict__ f,
                                                             const float* __restrict__ wT, float* __restrict__ dwT,
                                                             float* __restrict__ df, int B, int P, int Dout) {
   __shared__ float red[256];
@@ -235,22 +242,22 @@ __global__ void __launch_bounds__(256) masked_fc_bwd_kernel(const int* __restric
       for (; e + 4 <= e1; e += 4) {
         int t0 = first[cpaths[e]], t1 = first[cpaths[e + 1]], t2 = first[cpaths[e + 2]], t3 = first[cpaths[e + 3]];
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        f32x4 r0 = t0 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t0 * Dout + c4 * 4) : z;
-        f32x4 r1 = t1 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t1 * Dout + c4 * 4) : z;
-        f32x4 r2 = t2 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t2 * Dout + c4 * 4) : z;
-        f32x4 r3 = t3 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t3 * Dout + c4 * 4) : z;
+        f32x4 r0 = t0 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t0 * ldg + c4 * 4) : z;
+        f32x4 r1 = t1 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t1 * ldg + c4 * 4) : z;
+        f32x4 r2 = t2 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t2 * ldg + c4 * 4) : z;
+        f32x4 r3 = t3 >= 0 ? *reinterpret_cast<const f32x4*>(gout + (long long)t3 * ldg + c4 * 4) : z;
         S += r0;
-        if (t0 >= 0) for (int t = next[t0]; t >= 0; t = next[t]) S += *reinterpret_cast<const f32x4*>(gout + (long long)t * Dout + c4 * 4);
+        if (t0 >= 0) for (int t = next[t0]; t >= 0; t = next[t]) S += *reinterpret_cast<const f32x4*>(gout + (long long)t * ldg + c4 * 4);
         S += r1;
-        if (t1 >= 0) for (int t = next[t1]; t >= 0; t = next[t]) S += *reinterpret_cast<const f32x4*>(gout + (long long)t * Dout + c4 * 4);
+        if (t1 >= 0) for (int t = next[t1]; t >= 0; t = next[t]) S += *reinterpret_cast<const f32x4*>(gout + (long long)t * ldg + c4 * 4);
         S += r2;
-        if (t2 >= 0) for (int t = next[t2]; t >= 0; t = next[t]) S += *reinterpret_cast<const f32x4*>(gout + (long long)t * Dout + c4 * 4);
+        if (t2 >= 0) for (int t = next[t2]; t >= 0; t = next[t]) S += *reinterpret_cast<const f32x4*>(gout + (long long)t * ldg + c4 * 4);
         S += r3;
-        if (t3 >= 0) for (int t = next[t3]; t >= 0; t = next[t]) S += *reinterpret_cast<const f32x4*>(gout + (long long)t * Dout + c4 * 4);
+        if (t3 >= 0) for (int t = next[t3]; t >= 0; t = next[t]) S += *reinterpret_cast<const f32x4*>(gout + (long long)t * ldg + c4 * 4);
       }
       for (; e < e1; ++e)
         for (int t = first[cpaths[e]]; t >= 0; t = next[t])
-          S += *reinterpret_cast<const f32x4*>(gout + (long long)t * Dout + c4 * 4);
+          S += *reinterpret_cast<const f32x4*>(gout + (long long)t * ldg + c4 * 4);
       dw += S * f[cell];
     }
     __syncthreads();
@@ -266,13 +273,15 @@ __global__ void __launch_bounds__(256) masked_fc_bwd_kernel(const int* __restric
   if (valid) *reinterpret_cast<f32x4*>(dwT + ((long long)blockIdx.y * P + p) * Dout + c4 * 4) = dw;
 }
 
+// idx != NULL: target[i] = table[idx[i] * ld] (labels live in (N, 1) node tensors, src/train.py:519-521)
 __global__ void __launch_bounds__(1024) mse_kernel(const float* __restrict__ pred, const float* __restrict__ target, int n,
-                                                   float* __restrict__ loss, float* __restrict__ grad) {
+                                                   float* __restrict__ loss, float* __restrict__ grad,
+                                                   const int* __restrict__ idx, long long ld) {
   __shared__ double red[1024];
   double s = 0.0;
   float inv = 2.0f / (float)n;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    float d = pred[i] - target[i];
+    float d = pred[i] - (idx ? target[(long long)idx[i] * ld] : target[i]);
     s += (double)d * (double)d;
     if (grad) grad[i] = d * inv;
   }
@@ -434,10 +443,10 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
 // host) and the last workgroup to finish advances the counter - nothing step-dependent is uploaded by the host, so
 // a HIP-graph replay (or a host running several steps ahead of the device) cannot pair a step with another step's
 // scalars.
-__global__ void __launch_bounds__(256) adam_counted_kernel(float* __restrict__ p, const float* __restrict__ g,
+__global__ void __launch_bounds__(256) adam_counted_kernel(float* __restrict__ p, float* __restrict__ g,
                                                            float* __restrict__ m, float* __restrict__ v, long long n,
                                                            int* __restrict__ state, float lr, float beta1, float beta2,
-                                                           float eps, float wd, float gscale) {
+                                                           float eps, float wd, float gscale, int zero_grad) {
   const int t = state[0] + 1;
   const double bc1 = 1.0 - pow((double)beta1, (double)t);
   const double bc2 = 1.0 - pow((double)beta2, (double)t);
@@ -453,6 +462,7 @@ __global__ void __launch_bounds__(256) adam_counted_kernel(float* __restrict__ p
     p[i] = pi - step_size * (mi / denom);
     m[i] = mi;
     v[i] = vi;
+    if (zero_grad) g[i] = 0.f;                       // the next step's zero_grad() then costs no fill launch
   }
   __syncthreads();                                   // every thread of this workgroup has read state[0]
   if (threadIdx.x == 0) {
@@ -468,7 +478,34 @@ __global__ void __launch_bounds__(256) adam_counted_kernel(float* __restrict__ p
 
 using namespace mmft;
 
+// out[t][0 .. Da + Db + Dc) = a[t] | b[t] | c[t]; one float4 per thread
+__global__ void __launch_bounds__(256) concat_cols_kernel(const float* __restrict__ a, long long lda, int Da, const float* __restrict__ b,
+                                                          long long ldb, int Db, const float* __restrict__ c, long long ldc, int Dc,
+                                                          float* __restrict__ out, long long ldo, long long total) {
+  const int G = (Da + Db + Dc) / 4;
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+    const long long t = it / G;
+    const int col = (int)(it % G) * 4;
+    const float* src = col < Da ? a + t * lda + col : (col < Da + Db ? b + t * ldb + (col - Da) : c + t * ldc + (col - Da - Db));
+    *reinterpret_cast<f32x4*>(out + t * ldo + col) = *reinterpret_cast<const f32x4*>(src);
+  }
+}
+
 extern "C" {
+
+int mmft_concat_cols(const float* a, long long lda, int Da, const float* b, long long ldb, int Db, const float* c, long long ldc,
+                     int Dc, float* out, long long ldo, int T, int device, void* stream) {
+  MMFT_REQUIRE(a && b && out && T >= 0 && Da > 0 && Db > 0 && Dc >= 0 && (Dc == 0 || c), "concat_cols: bad arguments");
+  MMFT_REQUIRE(Da % 4 == 0 && Db % 4 == 0 && Dc % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && (Dc == 0 || ldc % 4 == 0) && ldo % 4 == 0 &&
+                   aligned16(a) && aligned16(b) && (!c || aligned16(c)) && aligned16(out),
+               "concat_cols: widths / strides must be multiples of 4, rows 16-byte aligned");
+  if (T == 0) return MMFT_OK;
+  DeviceGuard dg(device);
+  const long long total = (long long)T * ((Da + Db + Dc) / 4);
+  MMFT_LAUNCH("concat_cols_kernel", 0.0, 8.0 * T * (Da + Db + Dc), concat_cols_kernel, dim3(ew_grid(total)), dim3(256), (hipStream_t)stream, a,
+              lda, Da, b, ldb, Db, c, ldc, Dc, out, ldo, total);
+  return check_launch("concat_cols");
+}
 
 int mmft_transpose(const float* src, float* dst, int R, int C, int device, void* stream) {
   MMFT_REQUIRE(src && dst && R > 0 && C > 0, "transpose: bad args");
@@ -510,29 +547,69 @@ int mmft_masked_fc_fwd_runs(const int* run_ptr, const int* run_start, const int*
   MMFT_REQUIRE(aligned16(GP) && aligned16(out) && (!bias || aligned16(bias)), "masked_fc_fwd_runs: 16-byte alignment");
   DeviceGuard dg(device);
   MMFT_LAUNCH("masked_fc_fwd_runs_kernel", 0.0, 0.0, masked_fc_fwd_runs_kernel, dim3(T), dim3(256), (hipStream_t)stream, run_ptr,
-              run_start, run_len, paths, f_off, T, GP, bias, out, Dout, S);
+              run_start, run_len, paths, f_off, T, GP, bias, out, Dout, S, (long long)Dout);
   return check_launch("masked_fc_fwd_runs");
 }
 
-int mmft_masked_fc_bwd(const int* csc_indptr, const int* csc_paths, const int* first, const int* next, const float* gout,
+long long mmft_head_level_workspace_bytes(int T, int Dh, int Dc, int Da, int H1) {
+  return (long long)T * ((long long)Dh + Dc + Da + H1) * 4;
+}
+
+/* Predictions of ONE level call of PathModel.forward (src/model.py:269-292), without autograd state, as one entry point:
+ * z = [h[targets] | fcn(path_map) | mlp_alpha(level)] -> mlp_fuse (Linear - ReLU - Linear).  Five launches, no host work in
+ * between; the gradient of these predictions is produced later from the batched recomputation (model.LAZY_HEAD). */
+int mmft_head_level_fwd(const float* h, long long ldh, const int* targets, int T, int Dh, const int* run_ptr, const int* run_start,
+                        const int* run_len, const int* paths, const int* f_off, const float* GP, const float* fcn_bias, int Dc,
+                        int S, const float* alpha_row, int Da, const float* w1, const float* b1, int H1, const float* w2,
+                        const float* b2, int nout, float* workspace, long long workspace_bytes, float* out, int device, void* stream) {
+  MMFT_REQUIRE(T >= 0 && Dh > 0 && Dc > 0 && Da > 0 && H1 > 0 && nout > 0, "head_level_fwd: bad sizes");
+  if (T == 0) return MMFT_OK;
+  MMFT_REQUIRE(h && targets && run_ptr && run_start && run_len && paths && GP && alpha_row && w1 && w2 && out && workspace,
+               "head_level_fwd: null pointer");
+  MMFT_REQUIRE(workspace_bytes >= mmft_head_level_workspace_bytes(T, Dh, Dc, Da, H1) && aligned16(workspace) && Dh % 4 == 0 &&
+                   Dc % 4 == 0 && Da % 4 == 0,
+               "head_level_fwd: workspace too small / widths not multiples of 4");
+  const int Dz = Dh + Dc + Da;
+  float* z = workspace;
+  float* hid = workspace + (long long)T * Dz;
+  int rc = mmft_gather_rows(h, ldh, targets, T, Dh, z, Dz, device, stream);
+  if (rc) return rc;
+  {
+    MMFT_REQUIRE(aligned16(GP) && (!fcn_bias || aligned16(fcn_bias)), "head_level_fwd: 16-byte alignment");
+    DeviceGuard dg(device);
+    MMFT_LAUNCH("masked_fc_fwd_runs_kernel", 0.0, 0.0, masked_fc_fwd_runs_kernel, dim3(T), dim3(256), (hipStream_t)stream, run_ptr, run_start,
+                run_len, paths, f_off, T, GP, fcn_bias, z + Dh, Dc, S, (long long)Dz);
+    rc = check_launch("head_level_fwd: masked projection");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bcast_row_kernel, dim3(ew_grid((long long)T * Da)), dim3(256), 0, (hipStream_t)stream, alpha_row, Da, z + Dh + Dc,
+                       (long long)Dz, T);
+    rc = check_launch("head_level_fwd: level embedding");
+    if (rc) return rc;
+  }
+  rc = mmft_linear_fwd(z, nullptr, Dz, w1, Dz, b1, hid, nullptr, H1, T, H1, Dz, MMFT_EPI_STORE, MMFT_ACT_RELU, 0.f, device, stream);
+  if (rc) return rc;
+  return mmft_linear_fwd(hid, nullptr, H1, w2, H1, b2, out, nullptr, nout, T, nout, H1, MMFT_EPI_STORE, MMFT_ACT_NONE, 0.f, device, stream);
+}
+
+int mmft_masked_fc_bwd(const int* csc_indptr, const int* csc_paths, const int* first, const int* next, const float* gout, long long ldg,
                        const float* f, const float* wT, float* dwT, float* df, int B, int P, int Dout, float* workspace,
                        long long workspace_bytes, int device, void* stream) {
   MMFT_REQUIRE(csc_indptr && first && next && gout && f && wT && dwT && df, "masked_fc_bwd: null pointer");
   MMFT_REQUIRE(B > 0 && P > 0 && Dout >= 4 && Dout <= 1024 && Dout % 4 == 0,
                "masked_fc_bwd: Dout must be a multiple of 4 in [4, 1024]");
-  MMFT_REQUIRE(aligned16(gout) && aligned16(wT) && aligned16(dwT), "masked_fc_bwd: 16-byte alignment");
+  MMFT_REQUIRE(aligned16(gout) && aligned16(wT) && aligned16(dwT) && ldg >= Dout && ldg % 4 == 0, "masked_fc_bwd: 16-byte alignment");
   DeviceGuard dg(device);
   int groups = Dout / 4, cpb = 256 / groups;
   hipStream_t st = (hipStream_t)stream;
   if (B == 1) {
-    MMFT_LAUNCH("masked_fc_bwd_kernel", 0.0, 0.0, masked_fc_bwd_kernel, dim3(cdiv(P, cpb), 1), dim3(256), st, csc_indptr, csc_paths, first, next, gout, f, wT, dwT, df, B, P, Dout);
+    MMFT_LAUNCH("masked_fc_bwd_kernel", 0.0, 0.0, masked_fc_bwd_kernel, dim3(cdiv(P, cpb), 1), dim3(256), st, csc_indptr, csc_paths, first, next, gout, ldg, f, wT, dwT, df, B, P, Dout);
     return check_launch("masked_fc_bwd");
   }
   // one block column per design: B-fold parallelism; the per-design dwT slabs are summed in fixed order
   long long need = (long long)B * P * Dout * 4;
   MMFT_REQUIRE(workspace && workspace_bytes >= need && aligned16(workspace), "masked_fc_bwd: workspace too small");
   {
-    MMFT_LAUNCH("masked_fc_bwd_kernel", 0.0, 0.0, masked_fc_bwd_kernel, dim3(cdiv(P, cpb), B), dim3(256), st, csc_indptr, csc_paths, first, next, gout, f, wT, workspace, df, B, P, Dout);
+    MMFT_LAUNCH("masked_fc_bwd_kernel", 0.0, 0.0, masked_fc_bwd_kernel, dim3(cdiv(P, cpb), B), dim3(256), st, csc_indptr, csc_paths, first, next, gout, ldg, f, wT, workspace, df, B, P, Dout);
   }
   int rc = check_launch("masked_fc_bwd");
   if (rc) return rc;
@@ -543,7 +620,7 @@ long long mmft_masked_fc_bwd_runs_workspace_bytes(int B, int P, int Dout) {
   return B > 1 ? (long long)B * P * Dout * 4 : 0;                // per-design dwT slabs
 }
 
-int mmft_masked_fc_bwd_runs(const int* bnd_ptr, const int* bnd_code, const int* first, const int* next, const float* gout,
+int mmft_masked_fc_bwd_runs(const int* bnd_ptr, const int* bnd_code, const int* first, const int* next, const float* gout, long long ldg,
                             const float* f, const float* wT, float* dwT, float* df, int B, int P, int Dout, int S,
                             float* workspace, long long workspace_bytes, int device, void* stream) {
   MMFT_REQUIRE(bnd_ptr && bnd_code && first && next && gout && f && wT && dwT && df, "masked_fc_bwd_runs: null pointer");
@@ -552,7 +629,7 @@ int mmft_masked_fc_bwd_runs(const int* bnd_ptr, const int* bnd_code, const int* 
                    (groups & (groups - 1)) == 0 && S % (MFB_THREADS / groups) == 0 && (long long)S * Dout * 4 <= 65536,
                "masked_fc_bwd_runs: Dout / 4 must be a power of two <= 64, the block of S cells x Dout must fit 64 KB of "
                "LDS and S be a multiple of MFB_THREADS / (Dout / 4)");
-  MMFT_REQUIRE(aligned16(gout) && aligned16(wT) && aligned16(dwT), "masked_fc_bwd_runs: 16-byte alignment");
+  MMFT_REQUIRE(aligned16(gout) && aligned16(wT) && aligned16(dwT) && ldg >= Dout && ldg % 4 == 0, "masked_fc_bwd_runs: 16-byte alignment");
   MMFT_REQUIRE(B == 1 || (workspace && workspace_bytes >= mmft_masked_fc_bwd_runs_workspace_bytes(B, P, Dout) &&
                           aligned16(workspace)),
                "masked_fc_bwd_runs: workspace too small");
@@ -563,7 +640,7 @@ int mmft_masked_fc_bwd_runs(const int* bnd_ptr, const int* bnd_code, const int* 
   const size_t lds = (size_t)S * Dout * 4;
 #define MMFT_RUNS(G)                                                                                                   \
   MMFT_LAUNCH_LDS("masked_fc_bwd_runs_kernel", 0.0, 0.0, masked_fc_bwd_runs_kernel<G>, grid, dim3(MFB_THREADS), lds, st, bnd_ptr, \
-                  bnd_code, first, next, gout, f, wT, slabs, df, P, S)
+                  bnd_code, first, next, gout, ldg, f, wT, slabs, df, P, S)
   switch (groups) {
     case 1: MMFT_RUNS(1); break;
     case 2: MMFT_RUNS(2); break;
@@ -582,8 +659,16 @@ int mmft_masked_fc_bwd_runs(const int* bnd_ptr, const int* bnd_code, const int* 
 int mmft_mse_fwd_bwd(const float* pred, const float* target, int n, float* loss, float* grad, int device, void* stream) {
   MMFT_REQUIRE(pred && target && loss && n > 0 && n <= (1 << 24), "mse_fwd_bwd: bad args");
   DeviceGuard dg(device);
-  hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, target, n, loss, grad);
+  hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, target, n, loss, grad, (const int*)nullptr, 0LL);
   return check_launch("mse_fwd_bwd");
+}
+
+int mmft_mse_gather_fwd_bwd(const float* pred, const float* table, long long ld, const int* idx, int n, float* loss, float* grad,
+                            int device, void* stream) {
+  MMFT_REQUIRE(pred && table && idx && loss && n > 0 && n <= (1 << 24) && ld >= 1, "mse_gather_fwd_bwd: bad args");
+  DeviceGuard dg(device);
+  hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, table, n, loss, grad, idx, ld);
+  return check_launch("mse_gather_fwd_bwd");
 }
 
 int mmft_eval_sums(const float* pred, const float* arrival, const float* required, const float* label, int n, double* out,
@@ -626,13 +711,13 @@ int mmft_adam_step(float* p, const float* g, float* m, float* v, long long n, fl
   return check_launch("adam_step");
 }
 
-int mmft_adam_step_counted(float* p, const float* g, float* m, float* v, long long n, int* state, float lr, float beta1,
-                           float beta2, float eps, float weight_decay, float gscale, int device, void* stream) {
+int mmft_adam_step_counted(float* p, float* g, float* m, float* v, long long n, int* state, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, float gscale, int zero_grad, int device, void* stream) {
   MMFT_REQUIRE(p && g && m && v && state && n >= 0, "adam_step_counted: bad args");
   MMFT_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "adam_step_counted: betas must be in [0, 1)");
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
-  MMFT_LAUNCH("adam_kernel", 0.0, 28.0 * n, adam_counted_kernel, dim3(ew_grid(n)), dim3(256), (hipStream_t)stream, p, g, m, v, n, state, lr, beta1, beta2, eps, weight_decay, gscale);
+  MMFT_LAUNCH("adam_kernel", 0.0, (zero_grad ? 32.0 : 28.0) * n, adam_counted_kernel, dim3(ew_grid(n)), dim3(256), (hipStream_t)stream, p, g, m, v, n, state, lr, beta1, beta2, eps, weight_decay, gscale, zero_grad);
   return check_launch("adam_step_counted");
 }
 

@@ -807,6 +807,8 @@ inline int launch_gemm(const XL& xl, const WL& wl, const Epi& epi, int M, int N,
 
 // deterministic split-K combine: out[i] = (accumulate ? out[i] : 0) + sum_z slab[z][i], fixed z order
 int launch_slab_reduce(const float* slabs, int splits, long long elems, float* out, int accumulate, hipStream_t st);
+int launch_slab_reduce_strided(const float* slabs, int splits, long long stride, long long elems, float* out, int accumulate,
+                               hipStream_t st);
 
 }  // namespace mmft
 #include "gemm_bf16.h"

@@ -356,10 +356,23 @@ __global__ void __launch_bounds__(256) scatter_add_rows_sorted_kernel(float* __r
 // stride over the segment and their partial sums are combined through LDS in a fixed order.  For few, long segments
 // (the gradient of PathModel.mlp_alpha's level table: 64 rows x ~170 endpoints each) - one thread group per row walks
 // such a segment as a serial chain of dependent loads.
+// sorted_keys != NULL: segment v = the rows e of src with sorted_keys[e] == v (keys ascending: found by two binary searches,
+// no index arrays at all - the gradient of a table gathered with level-ordered indices).
+__device__ __forceinline__ int seg_lower_bound(const int* __restrict__ keys, int n, int v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys[mid] < v) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
 __global__ void __launch_bounds__(256) seg_sum_wg_kernel(const float* __restrict__ src, long long lds_,
                                                          const int* __restrict__ indptr, const int* __restrict__ indices,
                                                          const int* __restrict__ rows, int n, int D,
-                                                         float* __restrict__ out, long long ldo, int accumulate) {
+                                                         float* __restrict__ out, long long ldo, int accumulate,
+                                                         const int* __restrict__ sorted_keys, int nkeys) {
   __shared__ f32x4 part[64][4];                        // up to 64 thread groups x 4 float4 channel groups (D <= 16)...
   __shared__ f32x4 part2[32][64];                      // ...or up to 32 thread groups x 64 channel groups (D <= 256)
   const int groups = D >> 2, tgs = 256 / groups;
@@ -368,10 +381,11 @@ __global__ void __launch_bounds__(256) seg_sum_wg_kernel(const float* __restrict
   const int act = wide ? (tgs < 32 ? tgs : 32) : (tgs < 64 ? tgs : 64);
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     const int v = rows ? rows[i] : i;
-    const int e0 = indptr[v], e1 = indptr[v + 1];
+    const int e0 = sorted_keys ? seg_lower_bound(sorted_keys, nkeys, v) : indptr[v];
+    const int e1 = sorted_keys ? seg_lower_bound(sorted_keys, nkeys, v + 1) : indptr[v + 1];
     if (tg < act) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int e = e0 + tg; e < e1; e += act) acc += ld4(src + (long long)indices[e] * lds_ + c);
+      for (int e = e0 + tg; e < e1; e += act) acc += ld4(src + (long long)(indices ? indices[e] : e) * lds_ + c);
       if (wide) part2[tg][cg] = acc;
       else part[tg][cg] = acc;
     }
@@ -629,8 +643,21 @@ int mmft_seg_sum_rows_wg(const float* src, long long lds, const int* indptr, con
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
   MMFT_LAUNCH("seg_sum_wg_kernel", 0.0, 0.0, seg_sum_wg_kernel, dim3(n < 2048 ? n : 2048), dim3(256), (hipStream_t)stream, src,
-              lds, indptr, indices, rows, n, D, out, ldo, accumulate);
+              lds, indptr, indices, rows, n, D, out, ldo, accumulate, (const int*)nullptr, 0);
   return check_launch("seg_sum_rows_wg");
+}
+
+int mmft_seg_sum_sorted(const float* src, long long lds, const int* sorted_keys, int nsrc, int R, int D, float* out, long long ldo,
+                        int accumulate, int device, void* stream) {
+  MMFT_REQUIRE(src && sorted_keys && out && nsrc >= 0 && R > 0, "seg_sum_sorted: bad arguments");
+  MMFT_REQUIRE(D % 4 == 0 && D <= 256 && 256 % (D / 4) == 0 && lds >= D && ldo >= D && lds % 4 == 0 && ldo % 4 == 0 &&
+                   aligned16(src) && aligned16(out),
+               "seg_sum_sorted: D / 4 must divide 256 (D <= 256), rows 16-byte aligned");
+  DeviceGuard dg(device);
+  MMFT_LAUNCH("seg_sum_wg_kernel", (double)nsrc * D, 4.0 * ((double)nsrc * (D + 1) + 2.0 * R * D), seg_sum_wg_kernel,
+              dim3(R < 2048 ? R : 2048), dim3(256), (hipStream_t)stream, src, lds, (const int*)nullptr, (const int*)nullptr,
+              (const int*)nullptr, R, D, out, ldo, accumulate, sorted_keys, nsrc);
+  return check_launch("seg_sum_sorted");
 }
 
 int mmft_seg_sum_fwd(const float* src, long long lds, const int* indptr, const int* indices, const int* rows, int n,

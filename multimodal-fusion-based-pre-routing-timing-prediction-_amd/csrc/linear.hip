@@ -86,7 +86,7 @@ void prof_end(hipStream_t st) {
 // partials are combined through LDS in a fixed order -> bitwise reproducible for a given split count.
 template <int VEC>
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, int splits, long long elems,
-                                                          float* __restrict__ out, int accumulate) {
+                                                          float* __restrict__ out, int accumulate, long long stride) {
   __shared__ float part[16][16 * VEC + 1];
   const int zl = threadIdx.x >> 4, cg = threadIdx.x & 15;
   const long long i0 = ((long long)blockIdx.x * 16 + cg) * VEC;
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
   for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
   if (i0 < elems) {
     for (int z = zl; z < splits; z += 16) {
-      const float* q = slabs + (long long)z * elems + i0;
+      const float* q = slabs + (long long)z * stride + i0;
       if (VEC == 4) {
         f32x4 v = *reinterpret_cast<const f32x4*>(q);
         acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
@@ -118,16 +118,22 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
   }
 }
 
-int launch_slab_reduce(const float* slabs, int splits, long long elems, float* out, int accumulate, hipStream_t st) {
+// slab z starts at slabs + z * stride (stride >= elems: slabs that carry more than one result, e.g. [weights | column sums])
+int launch_slab_reduce_strided(const float* slabs, int splits, long long stride, long long elems, float* out, int accumulate,
+                               hipStream_t st) {
   const double by = 4.0 * (splits + 1.0) * elems;
-  if (elems % 4 == 0 && aligned16(slabs)) {
+  if (elems % 4 == 0 && stride % 4 == 0 && aligned16(slabs)) {
     MMFT_LAUNCH("slab_reduce_kernel", 0.0, by, slab_reduce_kernel<4>, dim3(cdiv(elems, 64)), dim3(256), st, slabs, splits,
-                elems, out, accumulate);
+                elems, out, accumulate, stride);
   } else {
     MMFT_LAUNCH("slab_reduce_kernel", 0.0, by, slab_reduce_kernel<1>, dim3(cdiv(elems, 16)), dim3(256), st, slabs, splits,
-                elems, out, accumulate);
+                elems, out, accumulate, stride);
   }
   return check_launch("slab_reduce");
+}
+
+int launch_slab_reduce(const float* slabs, int splits, long long elems, float* out, int accumulate, hipStream_t st) {
+  return launch_slab_reduce_strided(slabs, splits, elems, elems, out, accumulate, st);
 }
 
 // ---------------------------------------------------------------- column sums (bias gradients)

@@ -31,7 +31,10 @@ struct U16PackDesc {
 
 // out[((mb * taps + t) * KB + kb) * 64 * KW + lane * KW + j] = A_t[16 mb + r][4 KW kb + KW q + j],  lane = 16 q + r;
 // KW = 4 (v_mfma_f32_16x16x16_bf16 fragments) or 8 (16x16x32).  One thread per (fragment, lane, group of 4 k).
-__global__ void __launch_bounds__(256) u16_pack_kernel(const U16PackDesc* __restrict__ descs) {
+__global__ void __launch_bounds__(256) u16_pack_kernel(const U16PackDesc* __restrict__ descs, long long* __restrict__ counters,
+                                                       int ncounters, long long inc) {
+  // rides along: num_batches_tracked += inc for the network's BatchNorm layers (one launch less per forward)
+  if (counters && blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < ncounters) counters[threadIdx.x] += inc;
   const U16PackDesc d = descs[blockIdx.y];
   const int mode = d.mode & 3, KW = (d.mode & 4) ? 8 : 4, G = KW / 4;
   const int KB = d.K / (4 * KW), MB = d.rows / 16;
@@ -473,12 +476,14 @@ using namespace mmft;
 
 extern "C" {
 
-int mmft_u16_pack_weights(const void* descs, int n, long long max_frag_lanes, int device, void* stream) {
-  MMFT_REQUIRE(descs && n > 0 && max_frag_lanes > 0, "u16_pack_weights: bad arguments");
+int mmft_u16_pack_weights(const void* descs, int n, long long max_frag_lanes, long long* counters, int ncounters, long long inc,
+                          int device, void* stream) {
+  MMFT_REQUIRE(descs && n > 0 && max_frag_lanes > 0 && ncounters >= 0 && ncounters <= 256, "u16_pack_weights: bad arguments");
   DeviceGuard dg(device);
   long long gx = (max_frag_lanes + 255) / 256;
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(u16_pack_kernel, dim3((int)gx, n), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const U16PackDesc*>(descs));
+  MMFT_LAUNCH("u16_pack_kernel", 0.0, 6.0 * 4.0 * max_frag_lanes * n / 2, u16_pack_kernel, dim3((int)gx, n), dim3(256), (hipStream_t)stream,
+              reinterpret_cast<const U16PackDesc*>(descs), counters, ncounters, inc);
   return check_launch("u16_pack_weights");
 }
 

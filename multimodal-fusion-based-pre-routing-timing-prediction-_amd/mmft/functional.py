@@ -5,7 +5,7 @@ taken from the tensors / current stream at call time, and `backward(retain_graph
 (reference src/train.py:553) is tolerated because nothing is freed or mutated in backward.
 """
 import torch
-from . import ops, gradsink
+from . import ops, gradsink, lib
 
 
 class LinearActFn(torch.autograd.Function):
@@ -53,27 +53,67 @@ def linear_act(x, w, b=None, slope=None):
 
 
 class GatherRowsFn(torch.autograd.Function):
-    """out[i] = table[idx[i]] (idx int32 on the device); backward = segmented row sums in a fixed order for small
-    tables (bitwise reproducible), float atomics otherwise."""
+    """out[i] = table[idx[i]] (idx int32 on the device); backward = segmented row sums in a fixed order (bitwise
+    reproducible): by binary search when the caller states that idx is ascending (endpoints ordered by level), through a
+    stable sort otherwise.  Tables above 4096 rows are not on the reference path and are refused rather than summed with
+    float atomics."""
 
     @staticmethod
-    def forward(ctx, table, idx):
+    def forward(ctx, table, idx, ascending):
         t = table if table.is_contiguous() else table.contiguous()
-        ctx.shape = t.shape
+        if t.shape[0] > 4096:
+            raise NotImplementedError('gather_rows: tables above 4096 rows have no deterministic gradient kernel')
+        ctx.shape, ctx.ascending = t.shape, bool(ascending)
         ctx.save_for_backward(idx)
         return ops.gather_rows(t, idx)
 
     @staticmethod
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
+        gg = ops.strided_rows(g)                         # a column slice of the concatenated head input: read in place
+        D = ctx.shape[1]
+        if ctx.ascending and D % 4 == 0 and D <= 256 and 256 % (D // 4) == 0:
+            out = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+            lib.call('mmft_seg_sum_sorted', gg, gg.stride(0), idx, gg.shape[0], ctx.shape[0], D, out, out.stride(0), 0,
+                     *lib.stream_args(out))
+            return out, None, None
         out = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
-        gg = g if g.is_contiguous() else g.contiguous()
-        if ctx.shape[0] <= 4096:
-            ops.scatter_add_rows_det(out, idx, gg)       # small table, many duplicates: fixed summation order
-        else:
-            ops.scatter_add_rows(out, idx, gg)
-        return out, None
+        ops.scatter_add_rows_det(out, idx, gg)           # small table, many duplicates: fixed summation order
+        return out, None, None
 
 
-def gather_rows(table, idx):
-    return GatherRowsFn.apply(table, idx)
+class ConcatColsFn(torch.autograd.Function):
+    """torch.cat(parts, 1) of the fusion head (src/model.py:285-290) as one library launch; the backward hands out column
+    slices of the incoming gradient (views: the consumers read them with a row stride)."""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        ps = [ops._rows2d(p if p.stride(-1) == 1 else p.contiguous(), 'part') for p in parts]
+        T = ps[0].shape[0]
+        widths = [p.shape[1] for p in ps]
+        if any(p.shape[0] != T for p in ps) or any(w % 4 for w in widths) or not 2 <= len(ps) <= 3:
+            raise ValueError('concat_cols: two or three blocks of equal row count, widths multiples of 4')
+        ps = [p if (p.stride(0) % 4 == 0 and p.storage_offset() % 4 == 0) else p.contiguous() for p in ps]
+        out = torch.empty((T, sum(widths)), dtype=torch.float32, device=ps[0].device)
+        c = ps[2] if len(ps) == 3 else None
+        lib.call('mmft_concat_cols', ps[0], ps[0].stride(0), widths[0], ps[1], ps[1].stride(0), widths[1], c,
+                 c.stride(0) if c is not None else 0, widths[2] if c is not None else 0, out, out.stride(0), T, *lib.stream_args(out))
+        ctx.widths = widths
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, o = [], 0
+        for w in ctx.widths:
+            outs.append(g[:, o:o + w])
+            o += w
+        return tuple(outs)
+
+
+def concat_cols(*parts):
+    return ConcatColsFn.apply(*parts)
+
+
+def gather_rows(table, idx, ascending=False):
+    """ascending=True: the caller guarantees idx[i] <= idx[i + 1] (its gradient then needs no sort)."""
+    return GatherRowsFn.apply(table, idx, ascending)

@@ -185,6 +185,54 @@ def _fc_cached(kind, deps, build):
     return val
 
 
+def masked_fc_prefix(feat_map, w, masks):
+    """Block-prefix table GP[b * P + c] = sum of f * w^T over the cells <= c of c's RUN_BLOCK block (one launch pair per step and
+    feature map, cached), or None when the masks offer no run form.  Shared by MaskedFcFn and the one-call level head."""
+    f = feat_map.reshape(-1)
+    if not (USE_RUNS and masks.run_block and f.numel() == masks.B * masks.P and f.is_contiguous() and w.is_contiguous()):
+        return None
+    Dout, P = w.shape
+    dev, st = lib.stream_args(f)
+
+    def _wT():
+        t = torch.empty((P, Dout), dtype=torch.float32, device=f.device)
+        lib.call('mmft_transpose', w, t, Dout, P, dev, st)
+        return t
+    wT = _fc_cached('wT', (w,), _wT)
+
+    def _gp():
+        t = torch.empty((masks.B * P, Dout), dtype=torch.float32, device=f.device)
+        lib.call('mmft_masked_fc_prefix', f, wT, t, masks.B, P, Dout, masks.run_block, dev, st)
+        return t
+    return _fc_cached('GP', (w, feat_map), _gp)
+
+
+def head_level_forward(h, tix, pm, fcn, alpha_row, mlp_fuse):
+    """Predictions of one level call (no autograd state) through mmft_head_level_fwd, or None when the configuration is
+    outside that entry point (no run form, a head that is not Linear-ReLU-Linear)."""
+    mods = list(mlp_fuse.layers)
+    if len(mods) != 3 or not isinstance(mods[0], torch.nn.Linear) or not isinstance(mods[2], torch.nn.Linear) or \
+            getattr(mlp_fuse, 'negative_slope', 0) != 0 or not isinstance(fcn, torch.nn.Linear):
+        return None
+    w, b = fcn.weight.detach(), fcn.bias
+    GP = masked_fc_prefix(pm.feat_map.detach(), w, pm.masks)
+    if GP is None:
+        return None
+    m = pm.masks
+    T, Dh, Dc, Da = tix.numel(), h.shape[1], w.shape[0], alpha_row.numel()
+    l1, l2 = mods[0], mods[2]
+    if l1.in_features != Dh + Dc + Da or Dh % 4 or Dc % 4 or Da % 4 or not alpha_row.is_contiguous():
+        return None
+    H1, nout = l1.out_features, l2.out_features
+    out = torch.empty((T, nout), dtype=torch.float32, device=h.device)
+    ws = lib.workspace(h.device, lib.query('mmft_head_level_workspace_bytes', T, Dh, Dc, Da, H1))
+    dev, st = lib.stream_args(h)
+    lib.call('mmft_head_level_fwd', h, h.stride(0), tix, T, Dh, m.run_ptr, m.run_start, m.run_len, pm.paths, pm.f_off, GP,
+             b.detach() if b is not None else None, Dc, m.run_block, alpha_row, Da, l1.weight.detach(), l1.bias.detach() if l1.bias is not None else None,
+             H1, l2.weight.detach(), l2.bias.detach() if l2.bias is not None else None, nout, ws, ws.numel() * 4, out, dev, st)
+    return out.squeeze(-1)
+
+
 class MaskedFcFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat_map, w, b, pm):
@@ -228,7 +276,7 @@ class MaskedFcFn(torch.autograd.Function):
         f, wT = ctx.saved_tensors
         P, Dout = wT.shape
         pm = ctx.pm
-        g = gout if gout.is_contiguous() else gout.contiguous()
+        g = ops.strided_rows(gout)                       # a column slice of the concatenated head input: read in place
         dev, st = lib.stream_args(f)
         B = pm.masks.B
         dwT = torch.empty_like(wT)
@@ -244,11 +292,11 @@ class MaskedFcFn(torch.autograd.Function):
                 E = g.shape[0] * pm.masks.bnd_code.numel() / max(pm.masks.num_paths, 1)
                 lib.prof_hint(E * Dout + 4.0 * B * P * Dout,
                               min(E, float(g.shape[0])) * Dout * 4 + E * 4 + 2.0 * B * P * Dout * 4 + 12.0 * B * P)
-            lib.call('mmft_masked_fc_bwd_runs', pm.masks.bnd_ptr, pm.masks.bnd_code, pm.first, pm.next, g, f, wT, dwT, df,
+            lib.call('mmft_masked_fc_bwd_runs', pm.masks.bnd_ptr, pm.masks.bnd_code, pm.first, pm.next, g, g.stride(0), f, wT, dwT, df,
                      B, P, Dout, pm.masks.run_block, ws, ws.numel() * 4, dev, st)
         else:
             ws = lib.workspace(f.device, B * P * Dout * 4 if B > 1 else 0)
-            lib.call('mmft_masked_fc_bwd', pm.masks.csc_indptr, pm.masks.csc_paths, pm.first, pm.next, g, f, wT, dwT, df,
+            lib.call('mmft_masked_fc_bwd', pm.masks.csc_indptr, pm.masks.csc_paths, pm.first, pm.next, g, g.stride(0), f, wT, dwT, df,
                      B, P, Dout, ws, ws.numel() * 4, dev, st)
         dw = db = None
         if ctx.needs_input_grad[1]:
@@ -292,11 +340,56 @@ class MseFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gl):
         (grad,) = ctx.saved_tensors
-        return grad * gl, None
+        return (grad if is_unit_grad(gl) else grad * gl), None
+
+
+_UNIT = {}
+
+
+def unit_grad(device):
+    """A cached scalar 1.0 on `device` to seed backward() with (loss.backward(unit_grad(dev))): autograd then launches no
+    ones_like fill, and the loss Functions recognise it and skip the multiplication by the upstream gradient."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    t = _UNIT.get(key)
+    if t is None:
+        t = _UNIT[key] = torch.ones((), dtype=torch.float32, device=dev)
+    return t
+
+
+def is_unit_grad(g):
+    return any(g.data_ptr() == t.data_ptr() for t in _UNIT.values())
+
+
+class MseGatherFn(torch.autograd.Function):
+    """MSE(pred, table[idx]) with the gather inside the loss kernel (arrival_time[target_list], src/train.py:519-522)."""
+
+    @staticmethod
+    def forward(ctx, pred, table, idx):
+        p = pred if pred.is_contiguous() else pred.contiguous()
+        ops._chk(p, 'pred'); ops._chk(table, 'table')
+        if p.dim() != 1 or idx.dtype != torch.int32 or idx.numel() != p.numel() or not idx.is_contiguous() or table.dim() > 2 or \
+                (table.dim() == 2 and table.shape[1] != 1):
+            raise ValueError('mse_gather: pred (T,), table (N,) or (N, 1), idx int32 (T,)')
+        loss = torch.empty(1, dtype=torch.float32, device=p.device)
+        grad = torch.empty_like(p)
+        dev, st = lib.stream_args(p)
+        lib.call('mmft_mse_gather_fwd_bwd', p, table, table.stride(0), idx, p.numel(), loss, grad, dev, st)
+        ctx.save_for_backward(grad)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        (grad,) = ctx.saved_tensors
+        return (grad if is_unit_grad(gl) else grad * gl), None, None
 
 
 def mse_loss(pred, target):
     return MseFn.apply(pred, target)
+
+
+def mse_loss_gather(pred, table, idx):
+    return MseGatherFn.apply(pred, table, idx)
 
 
 class CrossEntropyFn(torch.autograd.Function):
@@ -345,7 +438,7 @@ class FlatAdam:
     torch's Adam skips them.
     """
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, buckets=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, buckets=None, zero_after_step=False):
         """buckets: optional [(name, [params...]), ...] partition of `params`; the flat buffers are laid out bucket
         after bucket, so each bucket is one contiguous range (one all-reduce + one Adam launch of its own, issued as
         soon as its gradients exist: mmft.dist.GradReducer).  Default: one bucket holding everything."""
@@ -361,6 +454,10 @@ class FlatAdam:
         if dev.type != 'cuda':
             raise RuntimeError('FlatAdam runs on the GPU only')
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        # zero_after_step: the Adam kernel clears the gradients it has consumed, so zero_grad() launches no fill (the .grad
+        # views then read zero after step(); keep False where the caller inspects gradients after the step)
+        self.zero_after_step = bool(zero_after_step)
+        self._cleared = [False] * len(buckets)
         # 16-byte aligned slots so that every view stays vector-load friendly
         self.offsets, off = [], 0
         self.bucket_ranges, self.bucket_params = [], []
@@ -393,7 +490,9 @@ class FlatAdam:
             gradsink.attach(p, p.grad)          # backward kernels store into the flat buffer directly
 
     def zero_grad(self):
-        self.flat_grad.zero_()
+        if not all(self._cleared):
+            self.flat_grad.zero_()
+        self._cleared = [False] * len(self._cleared)      # the backward pass is about to write them
         gradsink.new_step()
 
     def step_bucket(self, i, gscale=1.0):
@@ -405,7 +504,8 @@ class FlatAdam:
         dev, st = lib.stream_args(self.flat_param)
         lib.call('mmft_adam_step_counted', self.flat_param[lo:hi], self.flat_grad[lo:hi], self.m[lo:hi], self.v[lo:hi],
                  hi - lo, self.state[i], float(self.lr), float(b1), float(b2), float(self.eps), float(self.wd),
-                 float(gscale), dev, st)
+                 float(gscale), int(self.zero_after_step), dev, st)
+        self._cleared[i] = self.zero_after_step
         gradsink.params_changed()        # raw-pointer update: Tensor._version does not see it
 
     def step(self, gscale=1.0):

@@ -36,6 +36,14 @@ def _rows2d(t, name):
     return t
 
 
+def strided_rows(t):
+    """t itself when the kernels can read it as rows of a wider tensor (2-D, unit inner stride, rows 16-byte aligned - a column
+    slice of a concatenation's gradient), else a contiguous copy."""
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.storage_offset() % 4 == 0:
+        return t
+    return t.contiguous()
+
+
 def _idx(t, name, n=None):
     if t is None:
         return None
@@ -112,6 +120,9 @@ def linear_dgrad(g, w, dx=None, gidx=None, dxidx=None, M=None, mask=None, maskid
     return dx
 
 
+ROWS_OUTER = True       # bf16 mode: mmft_rows_outer_bf16 for the fc_cell_neigh weight gradients (False: the generic engine)
+
+
 def linear_wgrad(g, x, dw=None, gidx=None, xidx=None, rows=None, accumulate=False, db=None, with_bias=False):
     """dw[o][i] (+)= sum_r g[gidx[r]][o] * x[xidx[r]][i]; with_bias (or db given): also db[o] (+)= sum_r g[gidx[r]][o]
     from the same pass, and the pair (dw, db) is returned."""
@@ -129,12 +140,22 @@ def linear_wgrad(g, x, dw=None, gidx=None, xidx=None, rows=None, accumulate=Fals
     if tuple(dw.shape) != (out, inn):
         raise ValueError(f'linear_wgrad: dw shape {tuple(dw.shape)} != {(out, inn)}')
     dev, st = lib.stream_args(g)
-    if with_bias or db is not None:
+    want_db = with_bias or db is not None
+    if want_db:
         if db is None:
             db = torch.empty(out, dtype=torch.float32, device=g.device)
         _chk(db, 'db')
         if db.numel() != out or not db.is_contiguous():
             raise ValueError('linear_wgrad: db shape')
+    if ROWS_OUTER and gidx is None and xidx is None and rows >= 4096 and dw.is_contiguous() and g.stride(0) % 4 == 0 and \
+            x.stride(0) % 4 == 0 and lib.get_math_mode() == 'bf16' and lib.query('mmft_rows_outer_supported', out, inn):
+        # bf16 mode, plain row ranges, the 128 x 256 / 256 x 128 products of fc_cell_neigh: transposed LDS reads instead of
+        # the engine's in-register transposes
+        ws = lib.workspace(g.device, lib.query('mmft_rows_outer_workspace_bytes', rows, out, inn))
+        lib.call('mmft_rows_outer_bf16', g, g.stride(0), x, x.stride(0), dw, db if want_db else None, rows, out, inn, int(accumulate),
+                 ws, ws.numel() * 4, dev, st)
+        return (dw, db) if want_db else dw
+    if want_db:
         ws = lib.workspace(g.device, lib.query('mmft_linear_wgrad_bias_workspace_bytes', rows, out, inn))
         lib.call('mmft_linear_wgrad_bias', g, gidx, g.stride(0), x, xidx, x.stride(0), dw, dw.stride(0), db, rows, out,
                  inn, int(accumulate), ws, ws.numel() * 4, dev, st)
@@ -457,6 +478,15 @@ def scatter_add_rows_det(dst, idx, src):
     if name == 'mmft_seg_sum_rows_wg':
         lib.prof_hint(float(idx.numel()) * dst.shape[1], idx.numel() * (dst.shape[1] * 4 + 4) + 2.0 * R * dst.shape[1] * 4)
     lib.call(name, src, src.stride(0), indptr, perm.to(torch.int32), None, R, dst.shape[1], dst, dst.stride(0), 1, dev, st)
+    return dst
+
+
+def seg_sum_sorted(dst, sorted_idx, src):
+    """dst[v] += sum of src rows e with sorted_idx[e] == v; sorted_idx ascending int32 (the caller guarantees the order)."""
+    _rows2d(dst, 'dst'); _rows2d(src, 'src'); _idx(sorted_idx, 'sorted_idx', src.shape[0])
+    dev, st = lib.stream_args(dst)
+    lib.call('mmft_seg_sum_sorted', src, src.stride(0), sorted_idx, src.shape[0], dst.shape[0], dst.shape[1], dst, dst.stride(0), 1,
+             dev, st)
     return dst
 
 

@@ -247,7 +247,7 @@ class LevelFn(torch.autograd.Function):
         st, g, level_id, rows = ctx.state, ctx.state.graph, ctx.level_id, ctx.rows
         st.begin_backward()
         if ctx.tix.numel() and gout is not None:
-            go = gout if gout.is_contiguous() else gout.contiguous()
+            go = ops.strided_rows(gout)
             ops.scatter_add_targets(st.G, ctx.tix, go, unique=g.__dict__.get('targets_unique'))
         P = [_w(p) for p in st.params]
         (w1c, b1c, w2c, b2c, w1n, b1n, w2n, b2n, w1g, b1g, w2g, b2g) = P
@@ -394,9 +394,9 @@ def level_forward(conv, graph, cur_nodes, targets, level_id):
         if st.need_grad:
             st.spec_tix.append(tix)
             if graph.__dict__.get('_head_takes_gradients'):
-                # the caller (PathModel's deferred head) scatters the endpoint gradients itself from its root node: a
-                # plain gather, no autograd node per level
-                return ops.gather_rows(st.h, tix)
+                # the caller (PathModel's deferred head) gathers h[targets] inside its one-call level head and scatters the
+                # endpoint gradients itself from its root node: no launch, no autograd node here
+                return st.h.new_empty((tix.numel(), 0))
             return TargetGatherFn.apply(st.spec_token, st, tix, graph.__dict__.get('targets_unique'))
         return ops.gather_rows(st.h, tix)
     if level_id == 0 or graph._sweep is None:
@@ -583,7 +583,7 @@ class SweepFn(torch.autograd.Function):
         elif tix.numel():
             if fast:
                 ops.target_rows_begin(st.G, tix, st.tflag)
-            ops.scatter_add_targets(st.G, tix, gout if gout.is_contiguous() else gout.contiguous(),
+            ops.scatter_add_targets(st.G, tix, ops.strided_rows(gout),
                                     order=st.target_order, unique=st.targets_unique)
         P = [_w(p) for p in st.params]
         w1g, w2g = P[8], P[10]
@@ -628,7 +628,7 @@ class TargetGatherFn(torch.autograd.Function):
         st.begin_backward(zero_da=not fast, zero_g=not fast)
         if fast:
             ops.target_rows_begin(st.G, ctx.tix, st.tflag)
-        ops.scatter_add_targets(st.G, ctx.tix, gout if gout.is_contiguous() else gout.contiguous(), unique=ctx.unique)
+        ops.scatter_add_targets(st.G, ctx.tix, ops.strided_rows(gout), unique=ctx.unique)
         return st.h.new_zeros(1), None, None, None
 
 

@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from .pingraph import PinGraph
-from .fusion import PathMasks, MaskedPathMap, FlatAdam, mse_loss, cross_entropy_loss, batch_links
+from .fusion import PathMasks, MaskedPathMap, FlatAdam, mse_loss, mse_loss_gather, cross_entropy_loss, batch_links, unit_grad
 
 
 def build_models(map_size=128, out_dim=128, cell_feat_dim=36, net_feat_dim=2, cnn_outdim=128, pooling='max',
@@ -169,7 +169,8 @@ class DesignBatch:
 
 class TrainStep:
     def __init__(self, pmodel, cnn, designs, device, lr=1e-3, weight_decay=0.0, fused_optimizer=True, world_size=1,
-                 mode='sweep', overlap=True, with_optimizer=True, task='reg', cone=False, dense_path_map=False):
+                 mode='sweep', overlap=True, with_optimizer=True, task='reg', cone=False, dense_path_map=False,
+                 keep_grads=True):
         """mode='dropin': per-level model() calls exactly as src/train.py:490-511;
         mode='sweep': PathModel.forward_sweep, same arithmetic with level-invariant work hoisted.
         task='reg': MSE on the arrival time (nlabels = 1); task='cls': CrossEntropy on ndata['label'] with a
@@ -181,6 +182,8 @@ class TrainStep:
         # MaskedPathMap handle - what an UNMODIFIED caller loop passes; kept for measuring that form (bench.py)
         self.dense_path_map = bool(dense_path_map) and mode == 'dropin'
         self._sp_masks = None
+        # keep_grads=False: the fused Adam kernel clears the gradients it consumed (no zero_grad fill per step); .grad reads
+        # zero after step()
         # cone=True (sweep mode): the level kernels skip every node outside the fan-in cone of the step's endpoints
         # (device-side mask per step; pays when few endpoints of a large design are sampled, see sweep_forward_all)
         self.cone = bool(cone) and mode == 'sweep'
@@ -201,10 +204,11 @@ class TrainStep:
             if world_size > 1:
                 # data parallel: one flat range per gradient bucket, reduced as soon as its gradients exist
                 from .dist import GradReducer
-                self.optim = FlatAdam(params, lr=lr, weight_decay=weight_decay, buckets=parameter_buckets(pmodel, cnn))
+                self.optim = FlatAdam(params, lr=lr, weight_decay=weight_decay, buckets=parameter_buckets(pmodel, cnn),
+                                      zero_after_step=not keep_grads)
                 self.reducer = GradReducer(self.optim, world_size, device, side_stream=self.side)
             else:
-                self.optim = FlatAdam(params, lr=lr, weight_decay=weight_decay)
+                self.optim = FlatAdam(params, lr=lr, weight_decay=weight_decay, zero_after_step=not keep_grads)
         else:
             self.optim = torch.optim.Adam(params, lr, weight_decay=weight_decay)     # src/train.py:431-435
         pmodel.train()
@@ -281,7 +285,7 @@ class TrainStep:
         if self.task == 'cls':
             labels = self.batch.graph.ndata['label'][ends_d.long()].squeeze(-1).contiguous()
             return cross_entropy_loss(hats, labels)
-        return mse_loss(hats, self.batch.arrival[ends_d.long()].squeeze(-1))
+        return mse_loss_gather(hats, self.batch.arrival, ends_d)          # arrival_time[target_list], gathered in the kernel
 
     def step(self, path_ids_per_design):
         """One mini-batch: forward, MSE on arrival time, backward, (all-reduce,) Adam.
@@ -295,7 +299,7 @@ class TrainStep:
             # one delivery per parameter and step only in the whole-sweep form; the per-level loop adds into the head's
             # gradients once per level, so its buckets are reduced after backward() has returned
             self.reducer.begin(early=(self.mode == 'sweep'))
-            loss.backward()
+            loss.backward(unit_grad(self.device))
             self.reducer.finish()            # buckets not yet reduced; compute stream waits for the last Adam
         elif self.world_size > 1:
             from .dist import allreduce_sum_
@@ -306,7 +310,7 @@ class TrainStep:
                 g.mul_(1.0 / self.world_size)
             self.optim.step()
         else:
-            loss.backward()
+            loss.backward(unit_grad(self.device))       # cached scalar 1.0: no ones_like fill, no multiply in the loss backward
             self.optim.step()
         return loss.detach(), hats.detach(), ends_h.tolist()
 
@@ -370,6 +374,12 @@ class GraphedTrainStep:
         self.T = T
         sel = b.select(example_path_ids, static=self.static_idx)
         torch.cuda.synchronize()
+        if ts.optim.zero_after_step:
+            # the Adam launch of every replay leaves the gradients zero for the next one: start from that state, so that the
+            # captured zero_grad() records no fill
+            ts.optim.flat_grad.zero_()
+            ts.optim._cleared = [True] * len(ts.optim._cleared)
+            torch.cuda.synchronize()
         if self.pieces:
             self._capture_pieces(sel)
         else:
@@ -379,7 +389,7 @@ class GraphedTrainStep:
                 hats, ends_d, _ = ts.forward(None, _sel=sel)
                 loss = ts.loss(hats, ends_d)
                 ts.optim.zero_grad()
-                loss.backward()                      # data parallel: the buckets are reduced behind every replay
+                loss.backward(unit_grad(ts.device))  # data parallel: the buckets are reduced behind every replay
                 if ts.reducer is None:
                     ts.optim.step_captured()
                 self.loss, self.hats = loss.detach(), hats.detach()

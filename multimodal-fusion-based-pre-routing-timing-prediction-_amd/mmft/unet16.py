@@ -74,9 +74,10 @@ def pack_table(entries, device):
     return buf, table, offs, lanes
 
 
-def pack_run(buf, table, n, lanes):
+def pack_run(buf, table, n, lanes, counters=None, inc=0):
+    """counters: int64 vector bumped by `inc` in the same launch (the BatchNorm layers' num_batches_tracked)."""
     dev, st = lib.stream_args(buf)
-    lib.call('mmft_u16_pack_weights', table, n, lanes, dev, st)
+    lib.call('mmft_u16_pack_weights', table, n, lanes, counters, counters.numel() if counters is not None else 0, int(inc), dev, st)
 
 
 def conv_pack_entries(name, weight, backward=False):
@@ -121,12 +122,12 @@ class _Packs:
         self.buf, self.descs, self.off, self.lanes = pack_table(entries, self.device)
         self.n = len(entries)
 
-    def refresh(self, net):
+    def refresh(self, net, counters=None, inc=0):
         key = tuple(p.data_ptr() for p in net.parameters())
         if key != self.key:
             self._build(net)
             self.key = key
-        pack_run(self.buf, self.descs, self.n, self.lanes)
+        pack_run(self.buf, self.descs, self.n, self.lanes, counters, inc)
 
     def ptr(self, name):
         return self.buf.data_ptr() + self.off[name] * 2
@@ -198,7 +199,7 @@ class UNet16Fn(torch.autograd.Function):
         packs = net.__dict__.get('_u16_packs')
         if packs is None or packs.device != x.device:
             packs = net.__dict__['_u16_packs'] = _Packs(net, x.device)
-        packs.refresh(net)
+        packs.refresh(net, counters=net._batch_counters(), inc=N if net.inc.per_sample_stats else 1)
         xn = ops.to_nhwc(x)                                 # fp32 [N][H][W][3]
         sizes = [('z%d' % i, P[_CONV[i][2]] * _CONV[i][1]) for i in range(1, 15)]
         sizes += [('a1', P[0] * 16), ('cat3', P[0] * 32), ('p1', P[1] * 16), ('a3', P[1] * 32), ('cat2', P[1] * 64), ('p2', P[2] * 32),

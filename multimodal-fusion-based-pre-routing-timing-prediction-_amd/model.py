@@ -15,7 +15,8 @@ from torch import nn
 from mmft import functional as MF
 from mmft import sweep as _sweep
 from mmft import cnn as _cnn
-from mmft.fusion import MaskedPathMap, masked_fc
+from mmft import ops as _ops
+from mmft.fusion import MaskedPathMap, masked_fc, head_level_forward
 
 __all__ = ['MLP', 'PathConv', 'LayoutNet', 'PathModel', 'MaskedPathMap', 'th', 'nn']
 
@@ -172,8 +173,8 @@ class _HeadBatch:
             feat = self.feat_map.detach().requires_grad_(True)
             pm = MaskedPathMap(self.masks, paths, feat)
             h_cnn = m._fcn(pm)
-            h_global = MF.gather_rows(m.mlp_alpha(lvt), slot_of_row)
-            hats = m.mlp_fuse(th.cat((h_all, h_cnn, h_global), 1)).squeeze(-1)
+            h_global = MF.gather_rows(m.mlp_alpha(lvt), slot_of_row, ascending=True)
+            hats = m.mlp_fuse(MF.concat_cols(h_all, h_cnn, h_global)).squeeze(-1)
             params = [p for p in list(m.fcn.parameters()) + list(m.mlp_alpha.parameters()) + list(m.mlp_fuse.parameters())
                       if p.requires_grad]
             th.autograd.backward(hats, gr.reshape(hats.shape), inputs=[h_all, feat] + params)
@@ -204,11 +205,17 @@ class HeadLevelFn(th.autograd.Function):
     """Predictions of one level, computed without an autograd graph; backward parks the gradient in the batch."""
 
     @staticmethod
-    def forward(ctx, token, hb, slot, h_gnn, path_map, level_id_th):
+    def forward(ctx, token, hb, slot, tix, path_map, level_id_th):
         m = hb.model
-        k = h_gnn.shape[0]
-        h = th.cat((h_gnn, m._fcn(path_map), hb.alpha_of(slot, level_id_th).expand(k, m.global_dim)), 1)
         ctx.hb, ctx.slot = hb, slot
+        alpha = hb.alpha_of(slot, level_id_th)
+        # one C-ABI call per level: gather, masked projection, level embedding, mlp_fuse (mmft_head_level_fwd)
+        out = head_level_forward(hb.st.h, tix, path_map, m.fcn, alpha.detach().reshape(-1), m.mlp_fuse)
+        if out is not None:
+            return out
+        h_gnn = _ops.gather_rows(hb.st.h, tix)
+        k = h_gnn.shape[0]
+        h = th.cat((h_gnn, m._fcn(path_map), alpha.expand(k, m.global_dim)), 1)
         return m.mlp_fuse(h).squeeze(-1)
 
     @staticmethod
@@ -255,7 +262,7 @@ class PathModel(nn.Module):
                 hb.paths.append(path_map.paths)
                 hb.level_th.append(level_id_th)
                 hb.grads.append(None)
-                return HeadLevelFn.apply(hb.token, hb, slot, h_gnn.detach(), path_map, level_id_th)
+                return HeadLevelFn.apply(hb.token, hb, slot, st.spec_tix[-1], path_map, level_id_th)
             return self._fuse_level(h_gnn, self._fcn(path_map), target_list, level_id_th)
         if self.fcn is not None and len(target_list) != 0:
             h_cnn = self._fcn(path_map)
@@ -307,7 +314,13 @@ class PathModel(nn.Module):
         (= self._fcn(path_map)) so that the caller can overlap it with the tail of the sweep."""
         if h_cnn is None:
             h_cnn = self._fcn(path_map) if (self.fcn is not None and path_map is not None) else None
-        lv = th.arange(num_levels, dtype=th.float32, device=target_levels.device).unsqueeze(1)
-        h_global = MF.gather_rows(self.mlp_alpha(lv), target_levels)          # (T, 32), row = alpha(level of t)
+        cache = self.__dict__.setdefault('_level_ids', {})
+        key = (num_levels, str(target_levels.device))
+        lv = cache.get(key)
+        if lv is None:
+            lv = cache[key] = th.arange(num_levels, dtype=th.float32, device=target_levels.device).unsqueeze(1)
+        # endpoints arrive ordered by level (src/train.py:490-511 emits them level by level): the gradient of the gather is a
+        # segmented sum over contiguous runs
+        h_global = MF.gather_rows(self.mlp_alpha(lv), target_levels, ascending=True)   # (T, 32), row = alpha(level of t)
         parts = [p for p in (h_gnn, h_cnn, h_global) if p is not None]
-        return self.mlp_fuse(th.cat(parts, dim=1)).squeeze(-1)
+        return self.mlp_fuse(MF.concat_cols(*parts) if len(parts) > 1 else parts[0]).squeeze(-1)

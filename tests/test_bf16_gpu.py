@@ -368,3 +368,35 @@ def test_full_size_config_b_in_bf16_mode(dev):
     assert f[4] == a[4]                                                                       # same endpoints, same order
     assert rel_err(a[3], f[3]) < 5e-2                      # stated bf16 tolerance: first-step predictions vs the fp32 run
     assert rel_err(a[3], f[3]) > 1e-6                      # ... and bf16 mode really was a different arithmetic
+
+
+@pytest.mark.parametrize('out,inn,rows,ld_pad', [(128, 256, 5000, 0), (256, 128, 4099, 8), (128, 256, 70001, 0)])
+@pytest.mark.parametrize('representable', [True, False])
+def test_rows_outer_weight_gradient(dev, out, inn, rows, ld_pad, representable):
+    """mmft_rows_outer_bf16 (dw = g^T x, db = column sums of g; the fc_cell_neigh weight gradients of the bf16 mode, operands
+    transposed by ds_read_b64_tr_b16): exact layouts on bf16-representable operands, 2e-2 of the result's scale otherwise;
+    rows not a multiple of the 32-row step, padded leading dimensions, accumulate = 1; reached through ops.linear_wgrad."""
+    g = rnd(rows, out + ld_pad, seed=31, representable=representable)[:, :out]
+    x = rnd(rows, inn + ld_pad, seed=32, representable=representable)[:, :inn]
+    gd, xd = g.to(dev), x.to(dev)
+    if ld_pad:
+        gd = torch.zeros(rows, out + ld_pad, device=dev)[:, :out].copy_(g.to(dev))
+        xd = torch.zeros(rows, inn + ld_pad, device=dev)[:, :inn].copy_(x.to(dev))
+    lib.prof_reset()
+    lib.prof_enable(True)
+    dw, db = ops.linear_wgrad(gd, xd, with_bias=True)
+    torch.cuda.synchronize()
+    lib.prof_enable(False)
+    assert any(r['name'].startswith('rows_outer_kernel') for r in lib.prof_report())
+    gb, xb = bf(g).double(), bf(x).double()
+    tol = (1e-5 if rows > 20000 else 2e-6) if representable else TOL      # fp32 accumulation over up to 70 001 rows
+    assert rel_err(dw, gb.T @ xb) < tol
+    assert rel_err(db, g.double().sum(0)) < 1e-5                      # from the fp32 staging registers
+    dw2, db2 = ops.linear_wgrad(gd, xd, dw=dw.clone(), db=db.clone(), accumulate=True)
+    assert rel_err(dw2, 2 * (gb.T @ xb)) < tol and rel_err(db2, 2 * g.double().sum(0)) < 1e-5
+    ops.ROWS_OUTER = False
+    try:
+        dw3, _ = ops.linear_wgrad(gd, xd, with_bias=True)            # the generic engine, same math mode
+    finally:
+        ops.ROWS_OUTER = True
+    assert rel_err(dw3, dw) < (tol if representable else 1e-3)

@@ -31,6 +31,8 @@ def main():
     dev = torch.device('cuda', 0)
     designs = [synth_design(N=args.nodes, L=args.levels, tile=args.tile, seed=100 + i) for i in range(args.designs)]
     pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=9294)
+    from mmft import lib
+    lib.set_math_mode('bf16')
     ts = TrainStep(pmodel, cnn, designs, dev, mode='sweep', overlap=False)
     rng = np.random.default_rng(0)
     pick = lambda: [rng.permutation(d.num_paths)[:1350] for d in designs]
@@ -43,18 +45,21 @@ def main():
         torch.cuda.synchronize()
     sites = collections.defaultdict(collections.Counter)
     for ev in prof.events():
-        if not ev.name.startswith('aten::'):
-            continue
         if not (ev.kernels or []):
             continue
-        if ev.cpu_parent is not None and ev.cpu_parent.name.startswith('aten::'):
-            continue                                     # count the outermost aten op only
-        site = 'autograd engine / no python frame'
-        for fr in ev.stack or []:
-            if ROOT in fr and 'tools/trace_small_ops' not in fr:
-                site = fr.replace(ROOT + '/', '')
-                break
-        sites[ev.name][site] += 1
+        if not ev.name.startswith('aten::'):
+            continue
+        # attribute the launch to its outermost aten ancestor and the first frame of this repo on any ancestor's stack
+        root, site, cur = ev, None, ev
+        while cur is not None:
+            if cur.name.startswith('aten::'):
+                root = cur
+            for fr in cur.stack or []:
+                if site is None and ROOT in fr and 'tools/trace_small_ops' not in fr:
+                    site = fr.replace(ROOT + '/', '')
+            cur = cur.cpu_parent
+        kname = ','.join(sorted({k.name.split('<')[0].split('(')[0][-40:] for k in ev.kernels}))
+        sites[f'{root.name} -> {ev.name} [{kname}]'][site or 'autograd engine / no python frame'] += len(ev.kernels)
     for op, c in sorted(sites.items(), key=lambda kv: -sum(kv[1].values())):
         print(f'{op}: {sum(c.values())} launches/step')
         for site, n in c.most_common(12):
