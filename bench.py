@@ -80,11 +80,11 @@ def csrc_fingerprint():
     return h.hexdigest()
 
 
-PMC_TABLE = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm_traffic.json')
+PMC_TABLE = os.path.join(ROOT, 'profiles', 'r03_pmc_hbm_traffic.json')
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r02_pmc_hbm_traffic.json: separate
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r03_pmc_hbm_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this bench, KiB units, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  The table is stamped with the fingerprint of the kernel sources it was
     measured on: (None, reason) when the stamp does not match the sources in this tree or the kernel has no entry -
@@ -439,20 +439,24 @@ def main():
     # dense `path_mask.to_dense() * feat_map`
     dropin = {}
     if rank == 0 and world == 1 and args.mode == 'sweep' and not args.no_dropin:
+        import gc
+        gc.collect()
+        gc.freeze()     # the eager loop allocates python objects per level call: keep the designs' ~4 M list entries out of
+                        # every generation-2 collection it would otherwise trigger (tens of ms each)
         for key, dense in (('dropin_ms_per_step', False), ('dropin_dense_ms_per_step', True)):
             try:
                 pm3, cnn3 = build_models(map_size=designs[0].map_size, device=dev, seed=9294)
-                ts3 = TrainStep(pm3, cnn3, designs, dev, world_size=1, mode='dropin', dense_path_map=dense)
-                sched = HISTORY[:7]
-                for ids in sched[:2]:
+                ts3 = TrainStep(pm3, cnn3, designs, dev, world_size=1, mode='dropin', dense_path_map=dense, keep_grads=False)
+                sched = HISTORY[:(6 if dense else 13)]
+                for ids in sched[:3]:
                     ts3.step(ids)
                 torch.cuda.synchronize()
                 t3 = time.perf_counter()
-                for ids in sched[2:]:
+                for ids in sched[3:]:
                     ts3.step(ids)
                 torch.cuda.synchronize()
-                dropin[key] = (time.perf_counter() - t3) / max(len(sched) - 2, 1) * 1e3
-                log(f'{key}: {dropin[key]:.2f} ms ({len(sched) - 2} steps)')
+                dropin[key] = (time.perf_counter() - t3) / max(len(sched) - 3, 1) * 1e3
+                log(f'{key}: {dropin[key]:.2f} ms ({len(sched) - 3} steps)')
                 del ts3, pm3, cnn3
                 torch.cuda.empty_cache()
             except Exception as e:                       # noqa: BLE001 - an extra measurement must not cost the bench line

@@ -65,12 +65,17 @@ inline int ensure_dyn_lds(DynLdsOnce& once, const void* kernel, int bytes, const
 // instrumented kernel, aggregated per kernel name by mmft_prof_report.  Off by default (zero overhead
 // beyond one branch per launch).
 bool prof_on();
+// launches that are being recorded into a HIP graph cannot carry the profiler's events
+inline bool stream_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
 void prof_begin(const char* name, double flops, double bytes, hipStream_t st);
 void prof_end(hipStream_t st);
 struct ProfScope {
   hipStream_t st;
   bool on;
-  ProfScope(const char* name, double flops, double bytes, hipStream_t s) : st(s), on(prof_on()) {
+  ProfScope(const char* name, double flops, double bytes, hipStream_t s) : st(s), on(prof_on() && !stream_capturing(s)) {
     if (on) prof_begin(name, flops, bytes, st);
   }
   ~ProfScope() {
@@ -85,7 +90,7 @@ void prof_events(const char* name, double flops, double bytes, hipEvent_t* e0, h
 void prof_commit();
 #define MMFT_LAUNCH_LDS(name, flops, bytes, kernel, grid, block, lds, st, ...)                               \
   do {                                                                                                       \
-    if (mmft::prof_on()) {                                                                                   \
+    if (mmft::prof_on() && !mmft::stream_capturing(st)) {                                                    \
       hipEvent_t mmft_e0_, mmft_e1_;                                                                         \
       mmft::prof_events(name, flops, bytes, &mmft_e0_, &mmft_e1_);                                           \
       hipExtLaunchKernelGGL(kernel, grid, block, lds, st, mmft_e0_, mmft_e1_, 0, __VA_ARGS__);               \

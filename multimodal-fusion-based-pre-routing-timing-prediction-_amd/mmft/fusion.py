@@ -125,9 +125,12 @@ class MaskedPathMap:
     def __init__(self, masks, paths, feat_map, f_off=None, first=None, next_=None):
         self.masks = masks
         dev = feat_map.device
-        if not torch.is_tensor(paths):
-            paths = torch.as_tensor(np.asarray(paths), dtype=torch.int32)
-        self.paths = paths.to(torch.int32).to(dev).contiguous()
+        if torch.is_tensor(paths) and paths.dtype == torch.int32 and paths.device == dev and paths.is_contiguous():
+            self.paths = paths                                  # the usual case: a slice of the step's packed selection
+        else:
+            if not torch.is_tensor(paths):
+                paths = torch.as_tensor(np.asarray(paths), dtype=torch.int32)
+            self.paths = paths.to(torch.int32).to(dev).contiguous()
         if f_off is None and masks.B > 1:
             # feature-map offset of each row's design, looked up on the device (no host round trip per level call)
             rd = masks.__dict__.get('_row_off_dev')
@@ -207,30 +210,50 @@ def masked_fc_prefix(feat_map, w, masks):
     return _fc_cached('GP', (w, feat_map), _gp)
 
 
-def head_level_forward(h, tix, pm, fcn, alpha_row, mlp_fuse):
-    """Predictions of one level call (no autograd state) through mmft_head_level_fwd, or None when the configuration is
-    outside that entry point (no run form, a head that is not Linear-ReLU-Linear)."""
-    mods = list(mlp_fuse.layers)
-    if len(mods) != 3 or not isinstance(mods[0], torch.nn.Linear) or not isinstance(mods[2], torch.nn.Linear) or \
-            getattr(mlp_fuse, 'negative_slope', 0) != 0 or not isinstance(fcn, torch.nn.Linear):
-        return None
-    w, b = fcn.weight.detach(), fcn.bias
-    GP = masked_fc_prefix(pm.feat_map.detach(), w, pm.masks)
-    if GP is None:
-        return None
-    m = pm.masks
-    T, Dh, Dc, Da = tix.numel(), h.shape[1], w.shape[0], alpha_row.numel()
-    l1, l2 = mods[0], mods[2]
-    if l1.in_features != Dh + Dc + Da or Dh % 4 or Dc % 4 or Da % 4 or not alpha_row.is_contiguous():
-        return None
-    H1, nout = l1.out_features, l2.out_features
-    out = torch.empty((T, nout), dtype=torch.float32, device=h.device)
-    ws = lib.workspace(h.device, lib.query('mmft_head_level_workspace_bytes', T, Dh, Dc, Da, H1))
-    dev, st = lib.stream_args(h)
-    lib.call('mmft_head_level_fwd', h, h.stride(0), tix, T, Dh, m.run_ptr, m.run_start, m.run_len, pm.paths, pm.f_off, GP,
-             b.detach() if b is not None else None, Dc, m.run_block, alpha_row, Da, l1.weight.detach(), l1.bias.detach() if l1.bias is not None else None,
-             H1, l2.weight.detach(), l2.bias.detach() if l2.bias is not None else None, nout, ws, ws.numel() * 4, out, dev, st)
-    return out.squeeze(-1)
+class HeadLevelCtx:
+    """mmft_head_level_fwd with everything that is the same for all level calls of a step resolved ONCE (the prefix table,
+    raw pointers, sizes): a level call then costs one output allocation and one C call.  `ok` is False when the
+    configuration is outside that entry point (no run form of the masks, a head that is not Linear-ReLU-Linear)."""
+
+    def __init__(self, h, feat_map, masks, fcn, mlp_fuse, Da):
+        self.ok = False
+        mods = list(mlp_fuse.layers)
+        if len(mods) != 3 or not isinstance(mods[0], torch.nn.Linear) or not isinstance(mods[2], torch.nn.Linear) or \
+                getattr(mlp_fuse, 'negative_slope', 0) != 0 or not isinstance(fcn, torch.nn.Linear):
+            return
+        w, b = fcn.weight.detach(), fcn.bias
+        GP = masked_fc_prefix(feat_map.detach(), w, masks)
+        if GP is None:
+            return
+        l1, l2 = mods[0], mods[2]
+        Dh, Dc = h.shape[1], w.shape[0]
+        if l1.in_features != Dh + Dc + Da or Dh % 4 or Dc % 4 or Da % 4:
+            return
+        self.keep = (h, GP, masks, w, b, l1, l2)               # the tensors behind the raw pointers
+        self.h, self.Dh, self.Dc, self.Da, self.H1, self.nout = h, Dh, Dc, Da, l1.out_features, l2.out_features
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        self.head = (h.data_ptr(), h.stride(0))
+        self.mid = (masks.run_ptr.data_ptr(), masks.run_start.data_ptr(), masks.run_len.data_ptr())
+        self.tail_a = (GP.data_ptr(), ptr(b), Dc, masks.run_block)
+        self.tail_b = (Da, l1.weight.data_ptr(), ptr(l1.bias), self.H1, l2.weight.data_ptr(), ptr(l2.bias), self.nout)
+        self.dev, self.st = lib.stream_args(h)
+        self.fn = lib.load().mmft_head_level_fwd
+        self.ws, self.ws_rows = None, 0
+        self.ok = True
+
+    def run(self, tix, paths, f_off, alpha_row):
+        T = tix.numel()
+        if T > self.ws_rows:
+            self.ws_rows = max(T, 2 * self.ws_rows, 1024)
+            self.ws = lib.workspace(self.h.device, lib.query('mmft_head_level_workspace_bytes', self.ws_rows, self.Dh, self.Dc,
+                                                             self.Da, self.H1))
+        out = torch.empty((T, self.nout), dtype=torch.float32, device=self.h.device)
+        rc = self.fn(*self.head, tix.data_ptr(), T, self.Dh, *self.mid, paths.data_ptr(),
+                     f_off.data_ptr() if f_off is not None else None, *self.tail_a, alpha_row.data_ptr(), *self.tail_b,
+                     self.ws.data_ptr(), self.ws.numel() * 4, out.data_ptr(), self.dev, self.st)
+        if rc != 0:
+            raise RuntimeError(f"mmft_head_level_fwd failed ({rc}): {lib.load().mmft_last_error().decode()}")
+        return out.squeeze(-1)
 
 
 class MaskedFcFn(torch.autograd.Function):

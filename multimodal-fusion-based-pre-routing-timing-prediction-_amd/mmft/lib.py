@@ -83,16 +83,27 @@ def stream_args(t):
     return dev, torch.cuda.current_stream(dev).cuda_stream
 
 
+_FN = {}
+_Tensor = torch.Tensor
+
+
 def call(name, *args):
-    lib = load()
-    rc = getattr(lib, name)(*[_conv(a) for a in args])
+    """Call an `int mmft_*(...)` entry point: tensors are passed as their data pointers, everything else as is (ctypes
+    converts ints, floats, bools and None through the argtypes parsed from the header).  Hot on every eager launch: the
+    bound function is cached and the argument loop does one isinstance per argument."""
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(load(), name)
+    rc = fn(*[a.data_ptr() if isinstance(a, _Tensor) else a for a in args])
     if rc != 0:
-        raise RuntimeError(f"{name} failed ({rc}): {lib.mmft_last_error().decode()}")
+        raise RuntimeError(f"{name} failed ({rc}): {load().mmft_last_error().decode()}")
 
 
 def query(name, *args):
-    lib = load()
-    return int(getattr(lib, name)(*[_conv(a) for a in args]))
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(load(), name)
+    return int(fn(*[a.data_ptr() if isinstance(a, _Tensor) else a for a in args]))
 
 
 _workspace = {}

@@ -359,7 +359,8 @@ def level_forward(conv, graph, cur_nodes, targets, level_id):
         if len(seen) >= 2 and (spec is None or len(seen) >= len(spec)):
             spec = graph.__dict__['_spec_lists'] = list(seen)            # the previous sweep's lists, levels 0 .. k
         del seen[:]
-        if SPECULATE and spec is not None and not torch.is_tensor(cur_nodes) and _same_list(cur_nodes, spec[0]):
+        if SPECULATE and spec is not None and not graph.__dict__.get('_spec_disabled') and not torch.is_tensor(cur_nodes) \
+                and _same_list(cur_nodes, spec[0]):
             st, token = _run_sweep(conv, graph, spec, None)
             st.spec_lists, st.spec_token, st.spec_tix, st.next_level = spec, token, [], 0
             spec_active = True
@@ -384,9 +385,16 @@ def level_forward(conv, graph, cur_nodes, targets, level_id):
             graph._sweep = st = nst
             spec_active = False
         elif mismatch:
+            # training: the levels below were computed from identical lists, but the autograd node of the speculative sweep
+            # covers the recorded lists of ALL levels - this step cannot be completed.  Speculation is switched off for the
+            # graph, so re-running the step (and every later one) takes the strict per-level path.
+            graph.__dict__['_spec_lists'] = None
+            graph.__dict__['_spec_disabled'] = True
+            graph._sweep = None
             raise RuntimeError(f'PathConv: level {level_id} arrived with a node list that differs from the one this graph was '
                                f'swept with before - the speculative whole-sweep of the level-0 call used the recorded lists. '
-                               f'Set mmft.sweep.SPECULATE = False for loops whose level lists change between steps.')
+                               f'Speculation is now disabled for this graph: zero graph.ndata["h"] and run the step again '
+                               f'(mmft.sweep.SPECULATE = False avoids the first failure for loops whose level lists change).')
     if spec_active:
         tix = graph.level_rows(level_id, targets, 'targets')
         if not tix.numel():

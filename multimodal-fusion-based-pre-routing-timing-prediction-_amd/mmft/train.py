@@ -118,7 +118,7 @@ class DesignBatch:
         gp = np.concatenate([np.asarray(p, dtype=np.int64) + self.path_off[i]
                              for i, p in enumerate(path_ids_per_design)])
         lv = self.path2level[gp]
-        order = np.argsort(lv, kind='stable')
+        order = np.argsort(lv.astype(np.int16) if self.L < 32768 else lv, kind='stable')     # 16-bit keys: numpy's radix sort
         gp, lv = gp[order], lv[order]
         ends = self.path2endpoint[gp]
         counts = np.bincount(lv, minlength=self.L)
@@ -263,6 +263,9 @@ class TrainStep:
                 # per-level rows; the per-row feature-map offsets come from the packed selection (no lookup launch per
                 # level), the link lists are derived only if a per-level backward asks for them
                 path_map = MaskedPathMap(b.masks, paths_d[pos:pos + k], feat, foff_d[pos:pos + k] if b.B > 1 else None)
+                # the step's link lists (all levels, in level order) for the deferred head, which differentiates all levels
+                # as one batch: without them it derives the lists from a device-to-host copy of the rows
+                path_map.batch_links, path_map.batch_rows = b.links, (pos, paths_d.numel())
             cur = self.pmodel(g, b.level_nodes[level_id], None, targets, level_id, b.level_th[level_id], path_map)
             pos += k
             if cur is not None:

@@ -16,6 +16,7 @@ lib.get_math_mode() == 'bf16' and the input qualifies (`supported`); everything 
 """
 import ctypes
 import math
+import weakref
 
 import torch
 from torch import nn
@@ -36,8 +37,25 @@ def supported(net, x):
     return H % 8 == 0 and W % 32 == 0 and H >= 8
 
 
+def _params(net):
+    """list(net.parameters()), cached: walking the module tree costs ~80 us and the eager callers do it several times per
+    call.  (The Parameter OBJECTS are stable; optimizers re-home their .data, which the pointer keys below notice.)"""
+    ps = net.__dict__.get('_u16_param_list')
+    if ps is None:
+        ps = net.__dict__['_u16_param_list'] = list(net.parameters())
+    return ps
+
+
 # (name of the DoubleConv, index of the conv inside it) in forward order; conv i (1-based) = CONVS[i - 1]
 def _layers(net):
+    cached = net.__dict__.get('_u16_layers')
+    if cached is not None:
+        return cached
+    net.__dict__['_u16_layers'] = out = _layers_uncached(net)
+    return out
+
+
+def _layers_uncached(net):
     dcs = [net.inc, net.down1.maxpool_conv[1], net.down2.maxpool_conv[1], net.down3.maxpool_conv[1],
            net.up1.conv, net.up2.conv, net.up3.conv]
     out = []
@@ -122,11 +140,15 @@ class _Packs:
         self.buf, self.descs, self.off, self.lanes = pack_table(entries, self.device)
         self.n = len(entries)
 
-    def refresh(self, net, counters=None, inc=0):
-        key = tuple(p.data_ptr() for p in net.parameters())
+    def ensure(self, net):
+        """(Re)build the descriptor table when a parameter's storage moved - an H2D copy, so never inside a capture."""
+        key = tuple(p.data_ptr() for p in _params(net))
         if key != self.key:
             self._build(net)
             self.key = key
+
+    def refresh(self, net, counters=None, inc=0):
+        self.ensure(net)
         pack_run(self.buf, self.descs, self.n, self.lanes, counters, inc)
 
     def ptr(self, name):
@@ -188,149 +210,271 @@ _ACT = {1: ('a1', 16, None), 2: ('cat3', 32, 'p1'), 3: ('a3', 32, None), 4: ('ca
 _UP = {0: (128, 'a8', 'cat1', 64, 3), 1: (64, 'a10', 'cat2', 32, 2), 2: (32, 'a12', 'cat3', 16, 1)}
 
 
+def _fwd_sizes(N, H, W):
+    lv, P = _geometry(N, H, W)
+    sizes = [('z%d' % i, P[_CONV[i][2]] * _CONV[i][1]) for i in range(1, 15)]
+    sizes += [('a1', P[0] * 16), ('cat3', P[0] * 32), ('p1', P[1] * 16), ('a3', P[1] * 32), ('cat2', P[1] * 64), ('p2', P[2] * 32),
+              ('a5', P[2] * 64), ('cat1', P[2] * 128), ('p3', P[3] * 64), ('a7', P[3] * 128), ('a8', P[3] * 128), ('a9', P[2] * 64),
+              ('a10', P[2] * 64), ('a11', P[1] * 32), ('a12', P[1] * 32), ('a13', P[0] * 16), ('a14', P[0] * 16)]
+    per_img = ctypes.c_int(0)
+    tiles0 = lib.load().mmft_u16_conv_tiles(N, lv[0][0], lv[0][1], ctypes.byref(per_img))
+    fsizes = [('stats', tiles0 * 2 * 128)] + [('bnp%d' % i, 5 * N * _CONV[i][1]) for i in range(1, 15)]
+    return sizes, fsizes
+
+
+def _bwd_sizes(N, H, W):
+    lv, P = _geometry(N, H, W)
+    sizes = [('g%d' % i, P[_CONV[i][2]] * _CONV[i][1]) for i in range(1, 15)] + [('dz%d' % i, P[_CONV[i][2]] * _CONV[i][1]) for i in range(1, 15)]
+    sizes += [('gcat3', P[0] * 32), ('gcat2', P[1] * 64), ('gcat1', P[2] * 128), ('gp1', P[1] * 16), ('gp2', P[2] * 32), ('gp3', P[3] * 64)]
+    q = lib.query
+    ws_bytes = max([q('mmft_u16_outconv_bwd_workspace_bytes', N, H, W)] +
+                   [q('mmft_u16_bn_bwd_workspace_bytes', N, lv[_CONV[i][2]][0] * lv[_CONV[i][2]][1], _CONV[i][1]) for i in range(1, 15)] +
+                   [q('mmft_u16_conv3x3_wgrad_workspace_bytes', N, lv[_CONV[i][2]][0], lv[_CONV[i][2]][1], _CONV[i][0], _CONV[i][1])
+                    for i in range(1, 15)] +
+                   [q('mmft_u16_convt_wgrad_workspace_bytes', N, lv[u[4]][0], lv[u[4]][1], u[0]) for u in _UP.values()])
+    return sizes, ws_bytes
+
+
+def _run_forward(net, xn, pool_mode, packs, T, F, out, geom):
+    """Every launch of UNet.forward (src/Unet.py:110-119) on the given buffers, in order; the weight pack comes first."""
+    N, H, W = geom
+    dev, st = lib.stream_args(out)
+    lv, _ = _geometry(N, H, W)
+    convs = _layers(net)
+    ups = [net.up1.up, net.up2.up, net.up3.up]
+    packs.refresh(net, counters=net._batch_counters(), inc=N if net.inc.per_sample_stats else 1)
+    per_img = ctypes.c_int(0)
+    for i in range(1, 15):
+        Ci, Co, l, inp = _CONV[i]
+        h, w = lv[l]
+        cv, bn = convs[i - 1]
+        xin = xn if inp == 'x' else T[inp]
+        lib.load().mmft_u16_conv_tiles(N, h, w, ctypes.byref(per_img))
+        lib.call('mmft_u16_conv3x3', xin, 1 if inp == 'x' else 0, packs.ptr('f%d' % (i - 1)), T['z%d' % i], F['stats'], N, h, w,
+                 Ci, Co, dev, st)
+        lib.call('mmft_u16_bn_finalize', F['stats'], per_img.value, N, Co, h * w, float(bn.eps), bn.weight.detach(), bn.bias.detach(),
+                 F['bnp%d' % i], dev, st)
+        abuf_name, lda, pooled = _ACT[i]
+        lib.call('mmft_u16_bn_apply', T['z%d' % i], F['bnp%d' % i], T[abuf_name], lda, T[pooled] if pooled else None, N, h, w, Co,
+                 pool_mode, float(bn.momentum), bn.running_mean, bn.running_var, dev, st)
+        for k, (uCi, uin, cat, coff, ul) in _UP.items():
+            if uin == abuf_name:                        # the Up block's transposed convolution follows this layer
+                up = ups[k]
+                uh, uw = lv[ul]
+                lib.call('mmft_u16_convt_fwd', T[uin], packs.ptr('tf%d' % k), up.bias.detach() if up.bias is not None else None,
+                         T[cat].data_ptr() + coff * 2, 2 * (uCi // 2), N, uh, uw, uCi, dev, st)
+    oc = net.outc.conv[0]
+    lib.call('mmft_u16_outconv_fwd', T['a14'], oc.weight.detach(), oc.bias.detach() if oc.bias is not None else None, out, N, H, W,
+             pool_mode, dev, st)
+
+
+def _make_sinks(net):
+    """One _Sink per parameter, in a fixed order: decided BEFORE any launch so that the launch sequence itself has no
+    data-dependent host decisions (it is captured and replayed for the eager callers)."""
+    sinks = {}
+    oc = net.outc.conv[0]
+    sinks[id(oc.weight)] = _Sink(oc.weight, (16,), lambda t, p=oc.weight: t.reshape(p.shape))
+    if oc.bias is not None:
+        sinks[id(oc.bias)] = _Sink(oc.bias, (1,), lambda t, p=oc.bias: t.reshape(p.shape))
+    for i, (cv, bn) in enumerate(_layers(net), start=1):
+        Ci, Co = _CONV[i][0], _CONV[i][1]
+        sinks[id(bn.weight)] = _Sink(bn.weight, (Co,), lambda t: t)
+        sinks[id(bn.bias)] = _Sink(bn.bias, (Co,), lambda t: t)
+        sinks[id(cv.weight)] = _Sink(cv.weight, (Co, 3, 3, Ci), lambda t: t.permute(0, 3, 1, 2))
+    for k, up in enumerate([net.up1.up, net.up2.up, net.up3.up]):
+        uCi = _UP[k][0]
+        Co = uCi // 2
+        sinks[id(up.weight)] = _Sink(up.weight, (4 * Co, uCi), lambda t, Co=Co, uCi=uCi: t.reshape(2, 2, Co, uCi).permute(3, 2, 0, 1))
+        if up.bias is not None:
+            sinks[id(up.bias)] = _Sink(up.bias, (Co,), lambda t: t)
+    return sinks
+
+
+def _run_backward(net, xn, pool_mode, packs, T, F, g, G, ws, geom, sinks):
+    """Every launch of the U-Net's backward pass on the given buffers, in order."""
+    N, H, W = geom
+    dev, st = lib.stream_args(g)
+    lv, _ = _geometry(N, H, W)
+    convs = _layers(net)
+    ups = [net.up1.up, net.up2.up, net.up3.up]
+    oc = net.outc.conv[0]
+    s_w, s_b = sinks[id(oc.weight)], sinks.get(id(oc.bias)) if oc.bias is not None else None
+    if s_b is not None and s_b.accumulate != s_w.accumulate:
+        raise RuntimeError('unet16: OutConv weight / bias sinks out of step')
+    lib.call('mmft_u16_outconv_bwd', T['a14'], oc.weight.detach(), oc.bias.detach() if oc.bias is not None else None, g, G['g14'],
+             s_w.out, s_b.out if s_b is not None else None, int(s_w.accumulate), N, H, W, pool_mode, ws, ws.numel() * 4, dev, st)
+
+    def conv_backward(i):
+        Ci, Co, l, inp = _CONV[i]
+        h, w = lv[l]
+        cv, bn = convs[i - 1]
+        s_g, s_bt = sinks[id(bn.weight)], sinks[id(bn.bias)]
+        if s_g.accumulate != s_bt.accumulate:
+            raise RuntimeError('unet16: BatchNorm weight / bias sinks out of step')
+        lib.call('mmft_u16_bn_bwd', G['g%d' % i], T['z%d' % i], F['bnp%d' % i], G['dz%d' % i], s_g.out, s_bt.out, int(s_g.accumulate),
+                 N, h * w, Co, ws, ws.numel() * 4, dev, st)
+        s_cw = sinks[id(cv.weight)]
+        xin = xn if inp == 'x' else T[inp]
+        lib.call('mmft_u16_conv3x3_wgrad', xin, 1 if inp == 'x' else 0, G['dz%d' % i], s_cw.out, int(s_cw.accumulate), N, h, w, Ci, Co,
+                 ws, ws.numel() * 4, dev, st)
+        if inp == 'x':
+            return
+        tgt = {'cat1': 'gcat1', 'cat2': 'gcat2', 'cat3': 'gcat3', 'p1': 'gp1', 'p2': 'gp2', 'p3': 'gp3'}.get(inp)
+        if tgt is None:
+            tgt = 'g%d' % (i - 1)                      # plain activation of the previous convolution
+        lib.call('mmft_u16_conv3x3', G['dz%d' % i], 0, packs.ptr('b%d' % (i - 1)), G[tgt], None, N, h, w, Co, Ci, dev, st)
+
+    def up_backward(k, g_target):
+        uCi, uin, cat, coff, ul = _UP[k]
+        up = ups[k]
+        uh, uw = lv[ul]
+        Co = uCi // 2
+        gslice = G['g' + cat].data_ptr() + coff * 2
+        s_uw, s_ub = sinks[id(up.weight)], sinks.get(id(up.bias)) if up.bias is not None else None
+        if s_ub is not None and s_ub.accumulate != s_uw.accumulate:
+            raise RuntimeError('unet16: ConvTranspose2d weight / bias sinks out of step')
+        lib.call('mmft_u16_convt_wgrad', T[uin], gslice, 2 * Co, s_uw.out, s_ub.out if s_ub is not None else None, int(s_uw.accumulate),
+                 N, uh, uw, uCi, ws, ws.numel() * 4, dev, st)
+        lib.call('mmft_u16_convt_dgrad', gslice, 2 * Co, packs.ptr('tb%d' % k), G[g_target], N, uh, uw, uCi, dev, st)
+
+    def pool_backward(cat, C, l, gp, g_target):
+        h, w = lv[l]
+        lib.call('mmft_u16_pool_bwd', T[cat], 2 * C, G['g' + cat], 2 * C, G[gp], G[g_target], N, h, w, C, pool_mode, dev, st)
+
+    conv_backward(14); conv_backward(13); up_backward(2, 'g12')
+    conv_backward(12); conv_backward(11); up_backward(1, 'g10')
+    conv_backward(10); conv_backward(9); up_backward(0, 'g8')
+    conv_backward(8); conv_backward(7); pool_backward('cat1', 64, 2, 'gp3', 'g6')
+    conv_backward(6); conv_backward(5); pool_backward('cat2', 32, 1, 'gp2', 'g4')
+    conv_backward(4); conv_backward(3); pool_backward('cat3', 16, 0, 'gp1', 'g2')
+    conv_backward(2); conv_backward(1)
+
+
+REPLAY = True           # eager callers (the per-level drop-in loop): second and later calls replay captured HIP graphs
+
+
+class _Token:
+    __slots__ = ('__weakref__',)
+
+
+class _Replay:
+    """Static buffers and captured HIP graphs of one network on one input geometry, for callers that launch eagerly: the 55
+    forward and ~120 backward launches of the U-Net become one graph launch each from the second step on (the per-level
+    drop-in loop is bound by host launch time).  Never used while an outer capture is running (the whole-sweep
+    step is captured as a whole), while an earlier forward's activations are still waiting for their backward pass, or when
+    a parameter has no gradient sink (plain torch optimizers)."""
+
+    def __init__(self, key):
+        self.key, self.calls, self.bwd_calls = key, 0, 0
+        self.fwd = self.bwd = None
+        self.pending = None                 # weak reference to the token of the forward whose backward has not run yet
+
+    def busy(self):
+        return self.pending is not None and self.pending() is not None
+
+
+def _replay_for(net, x, pool_mode):
+    if not REPLAY or lib.PROF_ON or torch.cuda.is_current_stream_capturing() or not torch.is_grad_enabled():
+        return None                         # (the launch profiler wants to see every kernel: no replay while it is on)
+    if any(gradsink.of(p) is None for p in _params(net)):
+        return None
+    key = (tuple(x.shape), pool_mode, x.device, tuple(p.data_ptr() for p in _params(net)),
+           tuple(gradsink.of(p)[0].data_ptr() for p in _params(net)))
+    rp = net.__dict__.get('_u16_replay')
+    if rp is None or rp.key != key:
+        rp = net.__dict__['_u16_replay'] = _Replay(key)
+    return None if rp.busy() else rp
+
+
 class UNet16Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, net, pool_mode, *params):
+    def forward(ctx, x, net, pool_mode, rp, *params):
         N, _, H, W = x.shape
-        dev, st = lib.stream_args(x)
-        lv, P = _geometry(N, H, W)
+        geom = (N, H, W)
         convs = _layers(net)
-        ups = [net.up1.up, net.up2.up, net.up3.up]
+        if not all(bn.momentum is not None and bn.affine and bn.track_running_stats for _, bn in convs):
+            raise NotImplementedError('unet16: BatchNorm2d without momentum / affine / running statistics is not on the reference path')
         packs = net.__dict__.get('_u16_packs')
         if packs is None or packs.device != x.device:
             packs = net.__dict__['_u16_packs'] = _Packs(net, x.device)
-        packs.refresh(net, counters=net._batch_counters(), inc=N if net.inc.per_sample_stats else 1)
+        if rp is not None:
+            rp.calls += 1
+        if rp is not None and rp.calls >= 2:
+            if rp.fwd is None:                              # second call: static buffers, capture
+                packs.ensure(net)
+                fs, ffs = _fwd_sizes(N, H, W)
+                rp.x = torch.empty_like(x)
+                rp.xn = ops.empty_nhwc(N, 3, H, W, x.device)
+                rp.abuf, rp.T = _arena(fs, torch.bfloat16, x.device)
+                rp.fbuf, rp.F = _arena(ffs, torch.float32, x.device, align=4)
+                rp.out = torch.empty((N, 1, H // 2, W // 2), dtype=torch.float32, device=x.device)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                    dev, st = lib.stream_args(rp.x)
+                    lib.call('mmft_nchw_to_nhwc', rp.x, rp.xn, N, 3, H, W, 3, dev, st)
+                    _run_forward(net, rp.xn, pool_mode, packs, rp.T, rp.F, rp.out, geom)
+                rp.fwd = graph
+            rp.x.copy_(x)
+            rp.fwd.replay()
+            tok = _Token()
+            rp.pending = weakref.ref(tok)
+            ctx.net, ctx.pool_mode, ctx.geom = net, pool_mode, geom
+            ctx.keep = (rp.xn, rp.abuf, rp.T, rp.fbuf, rp.F, packs)
+            ctx.replay, ctx.token = rp, tok
+            return rp.out.clone()
         xn = ops.to_nhwc(x)                                 # fp32 [N][H][W][3]
-        sizes = [('z%d' % i, P[_CONV[i][2]] * _CONV[i][1]) for i in range(1, 15)]
-        sizes += [('a1', P[0] * 16), ('cat3', P[0] * 32), ('p1', P[1] * 16), ('a3', P[1] * 32), ('cat2', P[1] * 64), ('p2', P[2] * 32),
-                  ('a5', P[2] * 64), ('cat1', P[2] * 128), ('p3', P[3] * 64), ('a7', P[3] * 128), ('a8', P[3] * 128), ('a9', P[2] * 64),
-                  ('a10', P[2] * 64), ('a11', P[1] * 32), ('a12', P[1] * 32), ('a13', P[0] * 16), ('a14', P[0] * 16)]
-        abuf, T = _arena(sizes, torch.bfloat16, x.device)
-        per_img = ctypes.c_int(0)
-        tiles0 = lib.load().mmft_u16_conv_tiles(N, lv[0][0], lv[0][1], ctypes.byref(per_img))
-        fbuf, F = _arena([('stats', tiles0 * 2 * 128)] + [('bnp%d' % i, 5 * N * _CONV[i][1]) for i in range(1, 15)],
-                         torch.float32, x.device, align=4)
-        momentum_ok = all(bn.momentum is not None and bn.affine and bn.track_running_stats for _, bn in convs)
-        if not momentum_ok:
-            raise NotImplementedError('unet16: BatchNorm2d without momentum / affine / running statistics is not on the reference path')
-        src = {'x': xn}
-        for i in range(1, 15):
-            Ci, Co, l, inp = _CONV[i]
-            h, w = lv[l]
-            cv, bn = convs[i - 1]
-            xin = src[inp] if inp == 'x' else T[inp]
-            tiles = lib.load().mmft_u16_conv_tiles(N, h, w, ctypes.byref(per_img))
-            lib.call('mmft_u16_conv3x3', xin, 1 if inp == 'x' else 0, packs.ptr('f%d' % (i - 1)), T['z%d' % i], F['stats'], N, h, w,
-                     Ci, Co, dev, st)
-            lib.call('mmft_u16_bn_finalize', F['stats'], per_img.value, N, Co, h * w, float(bn.eps), bn.weight.detach(), bn.bias.detach(),
-                     F['bnp%d' % i], dev, st)
-            abuf_name, lda, pooled = _ACT[i]
-            lib.call('mmft_u16_bn_apply', T['z%d' % i], F['bnp%d' % i], T[abuf_name], lda, T[pooled] if pooled else None, N, h, w, Co,
-                     pool_mode, float(bn.momentum), bn.running_mean, bn.running_var, dev, st)
-            for k, (uCi, uin, cat, coff, ul) in _UP.items():
-                if uin == abuf_name:                        # the Up block's transposed convolution follows this layer
-                    up = ups[k]
-                    uh, uw = lv[ul]
-                    lib.call('mmft_u16_convt_fwd', T[uin], packs.ptr('tf%d' % k), up.bias.detach() if up.bias is not None else None,
-                             T[cat].data_ptr() + coff * 2, 2 * (uCi // 2), N, uh, uw, uCi, dev, st)
-        oc = net.outc.conv[0]
+        fs, ffs = _fwd_sizes(N, H, W)
+        abuf, T = _arena(fs, torch.bfloat16, x.device)
+        fbuf, F = _arena(ffs, torch.float32, x.device, align=4)
         out = torch.empty((N, 1, H // 2, W // 2), dtype=torch.float32, device=x.device)
-        lib.call('mmft_u16_outconv_fwd', T['a14'], oc.weight.detach(), oc.bias.detach() if oc.bias is not None else None, out, N, H, W,
-                 pool_mode, dev, st)
-        ctx.net, ctx.pool_mode, ctx.geom = net, pool_mode, (N, H, W)
+        _run_forward(net, xn, pool_mode, packs, T, F, out, geom)
+        ctx.net, ctx.pool_mode, ctx.geom = net, pool_mode, geom
         ctx.keep = (xn, abuf, T, fbuf, F, packs)
-        ctx.nparams = len(params)
+        ctx.replay, ctx.token = None, None
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        net, pool_mode = ctx.net, ctx.pool_mode
-        N, H, W = ctx.geom
+        net, pool_mode, geom = ctx.net, ctx.pool_mode, ctx.geom
+        N, H, W = geom
         xn, _abuf, T, _fbuf, F, packs = ctx.keep
         g = gout if gout.is_contiguous() else gout.contiguous()
-        dev, st = lib.stream_args(g)
-        lv, P = _geometry(N, H, W)
-        convs = _layers(net)
-        ups = [net.up1.up, net.up2.up, net.up3.up]
-        sizes = [('g%d' % i, P[_CONV[i][2]] * _CONV[i][1]) for i in range(1, 15)] + [('dz%d' % i, P[_CONV[i][2]] * _CONV[i][1]) for i in range(1, 15)]
-        sizes += [('gcat3', P[0] * 32), ('gcat2', P[1] * 64), ('gcat1', P[2] * 128), ('gp1', P[1] * 16), ('gp2', P[2] * 32), ('gp3', P[3] * 64)]
-        _gbuf, G = _arena(sizes, torch.bfloat16, g.device)
-        q = lambda name, *a: lib.query(name, *a)
-        ws_bytes = max([q('mmft_u16_outconv_bwd_workspace_bytes', N, H, W)] +
-                       [q('mmft_u16_bn_bwd_workspace_bytes', N, lv[_CONV[i][2]][0] * lv[_CONV[i][2]][1], _CONV[i][1]) for i in range(1, 15)] +
-                       [q('mmft_u16_conv3x3_wgrad_workspace_bytes', N, lv[_CONV[i][2]][0], lv[_CONV[i][2]][1], _CONV[i][0], _CONV[i][1])
-                        for i in range(1, 15)] +
-                       [q('mmft_u16_convt_wgrad_workspace_bytes', N, lv[u[4]][0], lv[u[4]][1], u[0]) for u in _UP.values()])
+        sinks = _make_sinks(net)
+        rp = ctx.replay
+        fresh = all(s.direct and not s.accumulate for s in sinks.values())
+        if rp is not None and fresh and not torch.cuda.is_current_stream_capturing():
+            rp.bwd_calls += 1
+            if rp.bwd_calls >= 2:
+                if rp.bwd is None:                          # second backward: static gradient buffers, capture
+                    gs, ws_bytes = _bwd_sizes(N, H, W)
+                    rp.g = torch.empty_like(g)
+                    rp.gbuf, rp.G = _arena(gs, torch.bfloat16, g.device)
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                        ws = lib.workspace(g.device, ws_bytes)
+                        _run_backward(net, xn, pool_mode, packs, T, F, rp.g, rp.G, ws, geom, sinks)
+                    rp.bwd = graph
+                rp.g.copy_(g)
+                rp.bwd.replay()
+                for s in sinks.values():
+                    s.done()
+                rp.pending = None
+                return (None, None, None, None) + (None,) * len(_params(net))
+        gs, ws_bytes = _bwd_sizes(N, H, W)
+        _gbuf, G = _arena(gs, torch.bfloat16, g.device)
         ws = lib.workspace(g.device, ws_bytes)
-        grads = {}
-
-        oc = net.outc.conv[0]
-        s_w = _Sink(oc.weight, (16,), lambda t: t.reshape(oc.weight.shape))
-        s_b = _Sink(oc.bias, (1,), lambda t: t.reshape(oc.bias.shape)) if oc.bias is not None else None
-        if s_b is not None and s_b.accumulate != s_w.accumulate:
-            raise RuntimeError('unet16: OutConv weight / bias sinks out of step')
-        lib.call('mmft_u16_outconv_bwd', T['a14'], oc.weight.detach(), oc.bias.detach() if oc.bias is not None else None, g, G['g14'],
-                 s_w.out, s_b.out if s_b is not None else None, int(s_w.accumulate), N, H, W, pool_mode, ws, ws.numel() * 4, dev, st)
-        grads[id(oc.weight)] = s_w.done()
-        if s_b is not None:
-            grads[id(oc.bias)] = s_b.done()
-
-        def conv_backward(i):
-            Ci, Co, l, inp = _CONV[i]
-            h, w = lv[l]
-            cv, bn = convs[i - 1]
-            s_g, s_bt = _Sink(bn.weight, (Co,), lambda t: t), _Sink(bn.bias, (Co,), lambda t: t)
-            if s_g.accumulate != s_bt.accumulate:
-                raise RuntimeError('unet16: BatchNorm weight / bias sinks out of step')
-            lib.call('mmft_u16_bn_bwd', G['g%d' % i], T['z%d' % i], F['bnp%d' % i], G['dz%d' % i], s_g.out, s_bt.out, int(s_g.accumulate),
-                     N, h * w, Co, ws, ws.numel() * 4, dev, st)
-            grads[id(bn.weight)], grads[id(bn.bias)] = s_g.done(), s_bt.done()
-            s_cw = _Sink(cv.weight, (Co, 3, 3, Ci), lambda t: t.permute(0, 3, 1, 2))
-            xin = xn if inp == 'x' else T[inp]
-            lib.call('mmft_u16_conv3x3_wgrad', xin, 1 if inp == 'x' else 0, G['dz%d' % i], s_cw.out, int(s_cw.accumulate), N, h, w, Ci, Co,
-                     ws, ws.numel() * 4, dev, st)
-            grads[id(cv.weight)] = s_cw.done()
-            if inp == 'x':
-                return
-            tgt = {'cat1': 'gcat1', 'cat2': 'gcat2', 'cat3': 'gcat3', 'p1': 'gp1', 'p2': 'gp2', 'p3': 'gp3'}.get(inp)
-            if tgt is None:
-                tgt = 'g%d' % (i - 1)                      # plain activation of the previous convolution
-            lib.call('mmft_u16_conv3x3', G['dz%d' % i], 0, packs.ptr('b%d' % (i - 1)), G[tgt], None, N, h, w, Co, Ci, dev, st)
-
-        def up_backward(k, g_target):
-            uCi, uin, cat, coff, ul = _UP[k]
-            up = ups[k]
-            uh, uw = lv[ul]
-            Co = uCi // 2
-            gslice = G['g' + cat].data_ptr() + coff * 2
-            s_uw = _Sink(up.weight, (4 * Co, uCi), lambda t: t.reshape(2, 2, Co, uCi).permute(3, 2, 0, 1))
-            s_ub = _Sink(up.bias, (Co,), lambda t: t) if up.bias is not None else None
-            if s_ub is not None and s_ub.accumulate != s_uw.accumulate:
-                raise RuntimeError('unet16: ConvTranspose2d weight / bias sinks out of step')
-            lib.call('mmft_u16_convt_wgrad', T[uin], gslice, 2 * Co, s_uw.out, s_ub.out if s_ub is not None else None, int(s_uw.accumulate),
-                     N, uh, uw, uCi, ws, ws.numel() * 4, dev, st)
-            grads[id(up.weight)] = s_uw.done()
-            if s_ub is not None:
-                grads[id(up.bias)] = s_ub.done()
-            lib.call('mmft_u16_convt_dgrad', gslice, 2 * Co, packs.ptr('tb%d' % k), G[g_target], N, uh, uw, uCi, dev, st)
-
-        def pool_backward(cat, C, l, gp, g_target):
-            h, w = lv[l]
-            lib.call('mmft_u16_pool_bwd', T[cat], 2 * C, G['g' + cat], 2 * C, G[gp], G[g_target], N, h, w, C, pool_mode, dev, st)
-
-        conv_backward(14); conv_backward(13); up_backward(2, 'g12')
-        conv_backward(12); conv_backward(11); up_backward(1, 'g10')
-        conv_backward(10); conv_backward(9); up_backward(0, 'g8')
-        conv_backward(8); conv_backward(7); pool_backward('cat1', 64, 2, 'gp3', 'g6')
-        conv_backward(6); conv_backward(5); pool_backward('cat2', 32, 1, 'gp2', 'g4')
-        conv_backward(4); conv_backward(3); pool_backward('cat3', 16, 0, 'gp1', 'g2')
-        conv_backward(2); conv_backward(1)
-        plist = list(net.parameters())
-        return (None, None, None) + tuple(grads.get(id(p)) for p in plist)
+        _run_backward(net, xn, pool_mode, packs, T, F, g, G, ws, geom, sinks)
+        grads = {k: s.done() for k, s in sinks.items()}
+        if rp is not None:
+            rp.pending = None
+        return (None, None, None, None) + tuple(grads.get(id(p)) for p in _params(net))
 
 
 def unet_forward(net, x):
     """UNet.forward (src/Unet.py:110-119) on the bf16-storage kernels; x: fp32 (N,3,H,W)."""
     pooling = net.down1.maxpool_conv[0]
     pool_mode = ops.POOL_MAX if isinstance(pooling, nn.MaxPool2d) else ops.POOL_AVG
-    return UNet16Fn.apply(x, net, pool_mode, *list(net.parameters()))
+    # the replay decision needs the caller's grad mode (inside Function.forward it is always off)
+    return UNet16Fn.apply(x, net, pool_mode, _replay_for(net, x, pool_mode), *_params(net))

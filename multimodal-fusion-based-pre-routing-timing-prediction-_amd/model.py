@@ -16,7 +16,7 @@ from mmft import functional as MF
 from mmft import sweep as _sweep
 from mmft import cnn as _cnn
 from mmft import ops as _ops
-from mmft.fusion import MaskedPathMap, masked_fc, head_level_forward
+from mmft.fusion import MaskedPathMap, masked_fc, HeadLevelCtx
 
 __all__ = ['MLP', 'PathConv', 'LayoutNet', 'PathModel', 'MaskedPathMap', 'th', 'nn']
 
@@ -140,9 +140,12 @@ class _HeadBatch:
     def __init__(self, model, graph, st, feat_map, masks):
         self.model, self.graph, self.st, self.feat_map, self.masks = model, graph, st, feat_map, masks
         self.tix, self.paths, self.level_th, self.grads = [], [], [], []
+        self.links = None               # (first, next) of the whole step when every level call carried them (TrainStep does)
+        self.link_rows = []
         self.token = HeadRootFn.apply(st.spec_token, feat_map, self)
         # mlp_alpha of every level in one launch pair: the level-id tensors of the previous step's calls are tried first
         # (the reference loop and TrainStep pass the same objects every step); a call with another tensor computes its own
+        self.fast = HeadLevelCtx(st.h, feat_map, masks, model.fcn, model.mlp_fuse, model.global_dim)
         prev = graph.__dict__.get('_head_level_th')
         self.alpha_src, self.alpha = None, None
         if prev and all(t.numel() == 1 for t in prev):
@@ -171,7 +174,13 @@ class _HeadBatch:
         with th.enable_grad():
             h_all = ops.gather_rows(st.h, tix).requires_grad_(True)
             feat = self.feat_map.detach().requires_grad_(True)
-            pm = MaskedPathMap(self.masks, paths, feat)
+            # the caller's link lists describe ALL rows of the step in level order: usable when every level is in this batch
+            links = (None, None)
+            if self.links is not None and len(self.link_rows) == len(self.grads) == len(slots) and self.link_rows and \
+                    [r[0] for r in self.link_rows] == [sum(counts[:i]) for i in range(len(counts))] and \
+                    self.link_rows[0][1] == sum(counts):
+                links = self.links
+            pm = MaskedPathMap(self.masks, paths, feat, None, *links)
             h_cnn = m._fcn(pm)
             h_global = MF.gather_rows(m.mlp_alpha(lvt), slot_of_row, ascending=True)
             hats = m.mlp_fuse(MF.concat_cols(h_all, h_cnn, h_global)).squeeze(-1)
@@ -185,8 +194,14 @@ class _HeadBatch:
             ops.target_rows_begin(st.G, tix, st.tflag)
         ops.scatter_add_targets(st.G, tix, h_all.grad, unique=self.graph.__dict__.get('targets_unique'))
         self.graph.__dict__['_head_level_th'] = list(self.level_th)
-        self.token = None                       # breaks the batch <-> root-node reference cycle
-        return feat.grad
+        # break the reference cycles batch <-> root node and batch <-> sweep state: the batch holds the CNN feature map, whose
+        # autograd node keeps the U-Net's activation arena (260 MB at config B) alive until a full garbage collection otherwise
+        dfeat = feat.grad
+        self.token = None
+        if st.__dict__.get('head_batch') is self:
+            del st.__dict__['head_batch']
+        self.st = self.feat_map = self.masks = self.graph = self.fast = None
+        return dfeat
 
 
 class HeadRootFn(th.autograd.Function):
@@ -209,10 +224,9 @@ class HeadLevelFn(th.autograd.Function):
         m = hb.model
         ctx.hb, ctx.slot = hb, slot
         alpha = hb.alpha_of(slot, level_id_th)
-        # one C-ABI call per level: gather, masked projection, level embedding, mlp_fuse (mmft_head_level_fwd)
-        out = head_level_forward(hb.st.h, tix, path_map, m.fcn, alpha.detach().reshape(-1), m.mlp_fuse)
-        if out is not None:
-            return out
+        if hb.fast.ok and alpha.is_contiguous():
+            # one C-ABI call per level: gather, masked projection, level embedding, mlp_fuse (mmft_head_level_fwd)
+            return hb.fast.run(tix, path_map.paths, path_map.f_off, alpha)
         h_gnn = _ops.gather_rows(hb.st.h, tix)
         k = h_gnn.shape[0]
         h = th.cat((h_gnn, m._fcn(path_map), alpha.expand(k, m.global_dim)), 1)
@@ -260,6 +274,10 @@ class PathModel(nn.Module):
                 slot = len(hb.grads)
                 hb.tix.append(st.spec_tix[-1])
                 hb.paths.append(path_map.paths)
+                bl = getattr(path_map, 'batch_links', None)
+                if bl is not None:
+                    hb.links = bl
+                    hb.link_rows.append(path_map.batch_rows)
                 hb.level_th.append(level_id_th)
                 hb.grads.append(None)
                 return HeadLevelFn.apply(hb.token, hb, slot, st.spec_tix[-1], path_map, level_id_th)

@@ -713,3 +713,79 @@ def test_reference_style_training_loop(dev):
     sd = cnn.state_dict()
     close(sd['inc.double_conv.1.running_var'], oracle.pc['inc.double_conv.1.running_var'], 1e-3, 'running_var')
     assert int(sd['inc.double_conv.1.num_batches_tracked']) == int(oracle.pc['inc.double_conv.1.num_batches_tracked'])
+
+
+def test_dropin_loop_with_changing_level_lists(dev):
+    """the drop-in loop speculates that a graph is swept with the same level lists every step.  A training step
+    whose list differs at a LATER level cannot be completed from the speculative sweep: it raises once, speculation is
+    switched off for that graph, and the same step run again (fresh h) takes the strict per-level path and equals the
+    whole-sweep entry on the same lists."""
+    from mmft.synth import synth_design
+    from mmft.train import build_models, TrainStep
+    from mmft.fusion import mse_loss
+    d = synth_design(N=2048, L=12, tile=32, seed=321, end_frac=0.25)
+    ids = [np.random.default_rng(3).permutation(d.num_paths)[:40].tolist()]
+    pmodel, cnn = build_models(map_size=d.map_size, device=dev, seed=7)
+    ts = TrainStep(pmodel, cnn, [d], dev, mode='dropin')
+    for _ in range(2):                                   # records the lists, then sweeps speculatively
+        ts.step(ids)
+    assert ts.batch.graph.__dict__.get('_spec_lists') is not None
+    full = list(ts.batch.level_nodes[5])
+    ts.batch.level_nodes[5] = list(reversed(full))       # same nodes, another list object with another order
+    with pytest.raises(RuntimeError, match='Speculation is now disabled'):
+        ts.step(ids)
+    assert ts.batch.graph.__dict__.get('_spec_disabled')
+    hats, ends_d, _ = ts.forward(ids)                    # the retry: strict per-level execution
+    loss = mse_loss(hats, ts.batch.arrival[ends_d.long()].squeeze(-1))
+    ts.optim.zero_grad()
+    loss.backward()
+    got = {k: p.grad.clone() for k, p in pmodel.named_parameters() if p.grad is not None}
+    state = {k: v.clone() for k, v in pmodel.state_dict().items()}, {k: v.clone() for k, v in cnn.state_dict().items()}
+    pm2, cnn2 = build_models(map_size=d.map_size, device=dev, seed=7)
+    pm2.load_state_dict(state[0]); cnn2.load_state_dict(state[1])
+    ts2 = TrainStep(pm2, cnn2, [d], dev, mode='sweep')
+    ts2.batch.level_nodes[5] = list(reversed(full))
+    hats2, ends2, _ = ts2.forward(ids)
+    loss2 = mse_loss(hats2, ts2.batch.arrival[ends2.long()].squeeze(-1))
+    ts2.optim.zero_grad()
+    loss2.backward()
+    close(hats, hats2, 1e-5, 'hats')
+    for k, g in got.items():
+        close(g, dict(pm2.named_parameters())[k].grad, 5e-5, 'grad ' + k)
+
+
+def test_dropin_unet_graph_replay_in_bf16_mode(dev):
+    """bf16 mode, eager callers: from the second step on UNet.forward / backward replay captured HIP graphs
+    (mmft.unet16._Replay).  Five drop-in steps with replay equal five steps without it bit for bit, an evaluation forward in
+    between (no-grad, other geometry) does not disturb it, and two forwards before a backward fall back to fresh buffers."""
+    from mmft import lib, unet16
+    from mmft.synth import synth_design
+    from mmft.train import build_models, TrainStep
+    d = synth_design(N=2048, L=12, tile=64, seed=322, end_frac=0.25)
+    rng = np.random.default_rng(4)
+    batches = [[rng.permutation(d.num_paths)[:40].tolist()] for _ in range(5)]
+    out = {}
+    with lib.math_mode('bf16'):
+        for replay in (True, False):
+            unet16.REPLAY = replay
+            try:
+                pmodel, cnn = build_models(map_size=d.map_size, device=dev, seed=9)
+                ts = TrainStep(pmodel, cnn, [d], dev, mode='dropin')
+                losses = []
+                for i, ids in enumerate(batches):
+                    losses.append(float(ts.step(ids)[0]))
+                    if i == 2:
+                        with torch.no_grad():
+                            cnn(torch.rand(1, 3, 32, 64, device=dev))
+                rp = cnn.__dict__.get('_u16_replay')
+                assert (rp is not None and rp.fwd is not None and rp.bwd is not None) == replay
+                out[replay] = (losses, ts.optim.flat_param.clone())
+                if replay:                                   # two forwards, then both backwards: the second takes fresh buffers
+                    x = ts.batch.images
+                    y1 = cnn(x)
+                    y2 = cnn(x)
+                    (y1.sum() + y2.sum()).backward()
+                    assert torch.equal(y1, y2)
+            finally:
+                unet16.REPLAY = True
+    assert out[True][0] == out[False][0] and torch.equal(out[True][1], out[False][1])

@@ -97,3 +97,29 @@ for it in range(12):
     print({k: (round(v * 1e3, 2) if isinstance(v, float) else v) for k, v in _T.items()}); _T.clear()
     print(f'forward: host issue {1e3 * (t1 - t0):6.2f} ms, done {1e3 * (t2 - t0):6.2f} ms | backward: host issue {1e3 * (t3 - t2):6.2f} ms, '
           f'done {1e3 * (t4 - t2):6.2f} ms | adam {1e3 * (t5 - t4):5.2f} ms')
+if os.environ.get('PROFILE'):
+    import cProfile, pstats, io
+    for what in ('forward', 'backward'):
+        p = ids()
+        torch.cuda.synchronize()
+        pr = cProfile.Profile()
+        if what == 'forward':
+            pr.enable()
+            hats, ends_d, ends_h = ts.forward(p)
+            loss = ts.loss(hats, ends_d)
+            pr.disable()
+            ts.optim.zero_grad(); loss.backward(); ts.optim.step()
+        else:
+            hats, ends_d, ends_h = ts.forward(p)
+            loss = ts.loss(hats, ends_d)
+            ts.optim.zero_grad()
+            torch.cuda.synchronize()
+            pr.enable()
+            loss.backward()
+            pr.disable()
+            ts.optim.step()
+        torch.cuda.synchronize()
+        sio = io.StringIO()
+        pstats.Stats(pr, stream=sio).strip_dirs().sort_stats('tottime').print_stats(45)
+        print('==== cProfile of one', what, '(main thread only)')
+        print('\n'.join(l[:150] for l in sio.getvalue().splitlines()[:70]))

@@ -1,4 +1,4 @@
-"""rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (separate runs, CSV) -> profiles/r02_pmc_hbm_traffic.json.
+"""rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (separate runs, CSV) -> profiles/rNN_pmc_hbm_traffic.json.
 
     python tools/pmc_to_json.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [steps]
 Per kernel name: launches, FETCH_SIZE * 1024 * 2 (KiB units; gfx950 reports half the bytes of wide coalesced reads,
