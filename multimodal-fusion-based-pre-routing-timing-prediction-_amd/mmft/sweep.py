@@ -398,7 +398,10 @@ def level_forward(conv, graph, cur_nodes, targets, level_id):
     if spec_active:
         tix = graph.level_rows(level_id, targets, 'targets')
         if not tix.numel():
-            return st.h.new_zeros((0, st.D))
+            e = st.__dict__.get('_empty_rows')
+            if e is None:
+                e = st.__dict__['_empty_rows'] = st.h.new_zeros((0, st.D))
+            return e
         if st.need_grad:
             st.spec_tix.append(tix)
             if graph.__dict__.get('_head_takes_gradients'):

@@ -263,7 +263,10 @@ class PathModel(nn.Module):
         if self._lazy_ok(graph, target_list, path_map):
             graph.__dict__['_head_takes_gradients'] = True                     # speculative sweep: plain gather of h[targets]
             try:
-                h_gnn = self.gnn(graph, nodes, eids, target_list, level_id)    # advances the (speculative) sweep
+                # advances the (speculative) sweep; the module's forward is called directly when no hooks are registered
+                # (64 calls per step: nn.Module.__call__ costs as much as the level bookkeeping itself)
+                gnn = self.gnn
+                h_gnn = (gnn.forward if not (gnn._forward_hooks or gnn._forward_pre_hooks) else gnn)(graph, nodes, eids, target_list, level_id)
             finally:
                 graph.__dict__['_head_takes_gradients'] = False
             st = graph._sweep
