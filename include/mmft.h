@@ -77,6 +77,10 @@ long long mmft_linear_wgrad_workspace_bytes(int rows, int out, int in);
 int mmft_linear_wgrad(const float* g, const int* gidx, long long ldg, const float* x, const int* xidx,
                       long long ldx, float* dw, long long lddw, int rows, int out, int in, int accumulate,
                       float* workspace, long long workspace_bytes, int device, void* stream);
+/* n <= 24 slab reductions in ONE launch: out[i] (+)= sum over slabs z and over `fold` consecutive segments f of
+ * slabs[z * stride + f * elems + i].  table (HOST memory) = n rows of seven 64-bit integers: slabs (device pointer), out
+ * (device pointer), splits, stride (floats between slabs), elems, fold (>= 1), accumulate.  Fixed summation order. */
+int mmft_slab_reduce_batch(const long long* table, int n, int device, void* stream);
 /* same GEMM, and db[o] (+)= sum_r g[gidx[r]][o] from the fragments of g the kernel already holds: weight AND bias
  * gradient of one th.nn.Linear (src/model.py:13-14) from a single pass over g */
 long long mmft_linear_wgrad_bias_workspace_bytes(int rows, int out, int in);
@@ -140,6 +144,26 @@ int mmft_level_fwd_slots(float* h, const float* pre, long long ld, int D, const 
                          int n_net, int cell_row0, int n_cell, float* A, float* LSE, const void* w1_bf16, const float* b1,
                          const void* w2_bf16, const float* b2, float* hid_out, long long ldhid, int relu,
                          const unsigned char* active, long long alg_bytes, int device, void* stream);
+/* Reverse sweep of one (cell level l, net level l + 1) pair in ONE launch (three before: mmft_level_bwd_pull on each level and
+ * mmft_mlp2_rows_bf16 in its reverse form) - the autograd mirror of graph.pull + the cell MLP, src/model.py:100-117,138-146,186-187:
+ *   net rows w (sinks):   G[w] = relu'(h[w]) ((own[w] ? G[w] : 0) + sum_c DA[c] exp(h[w] - LSE[c]) (1 + h[w] - A[c]))
+ *   cell rows v (drivers): G[v] = relu'(h[v]) ((own[v] ? G[v] : 0) + sum of G[w] over v's sinks);
+ *                          DA[v] = ((G[v] W2g) * relu'(HN[v])) W1g, hidden gradient rows kept in hid_out (may be NULL).
+ * Precondition, checked by the caller (PinGraph.level_bwd_pairs): level l is a contiguous id range whose out-net edges in CSR
+ * order are exactly the id range of level l + 1 (sink of CSR position e = row e + sink_shift).  cslots int32[N][4] = the first
+ * four cell consumers of a net row in out-edge order (-1 = none); a row with more has slot 3 = -2 - (out-cell CSR position of
+ * its fourth consumer) and the kernel walks the CSR from there.  tiles int32[ntiles][8] = (first driver id, count <= 16, part,
+ * parts, first scratch row, counter index, first and end out-net CSR position of the tile's sinks), one workgroup each: parts = 0
+ * is a tile of whole drivers; a HEAVY driver (more sinks than a tile's target) is cut into `parts` tiles that leave their partial sums in scratch
+ * (fp32 [rows][128]) and count themselves in counters[counter index] (int32, zero before the first call, left zero) - the
+ * part that arrives last adds the partial sums in part order and finishes the driver (no waiting, no float atomics, the result
+ * does not depend on the arrival order).  has_mlp = 0: the two pulls only (level 0).  Tiles of whole drivers add in the order
+ * of mmft_level_bwd_pull without its heavy-row path: bitwise equal.  D = 128 only. */
+int mmft_level_bwd_pair(float* G, const float* h, const float* A, const float* LSE, float* DA, long long ld, int D, int N,
+                        const unsigned char* own_mask, const int* tiles, int ntiles, const int* out_net_indptr, int sink_shift,
+                        const int* cslots, const int* out_cell_indptr, const int* out_cell_indices, float* scratch, int* counters,
+                        int relu, int has_mlp, const void* w1_bf16, const void* w2_bf16, const float* mask, long long ldmask,
+                        float* hid_out, long long ldhid, long long alg_bytes, int device, void* stream);
 /* MMFT_MATH_BF16: the feature MLPs fc_cell_self / fc_net_self (Linear(fin, 256)-ReLU-Linear(256, 128) over the contiguous node
  * rows row0 .. row0 + n - 1; src/model.py:48-51,66-67,148-153,186-189) WITHOUT a stored hidden tensor.
  *   fwd: out[row] = (relu)(W2 relu(W1 x[row] + b1) + b2); x [.][ldx >= fin] and out [.][ldout] are indexed by NODE id.
@@ -521,7 +545,12 @@ int mmft_u16_pack_weights(const void* descs, int n, long long max_frag_lanes, lo
 int mmft_u16_conv_tiles(int N, int H, int W, int* per_image);
 int mmft_u16_conv3x3(const void* x, int rgb_f32, const void* wpk, void* y, float* stats, int N, int H, int W, int Ci, int Co,
                      int device, void* stream);
+/* Weight gradients: every workgroup leaves one partial result (a SLAB) in `workspace`; with dw != NULL the call also adds
+ * the slabs up (in a fixed order) into dw, with dw == NULL they stay in `workspace` and the caller reduces several layers'
+ * slabs with ONE mmft_slab_reduce_batch launch (nothing needs a U-Net weight gradient before the optimizer).
+ * *_slabs: the number of slabs; conv3x3: Co * 9 * Ci floats each. */
 long long mmft_u16_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Ci, int Co);
+int mmft_u16_conv3x3_wgrad_slabs(int N, int H, int W, int Ci, int Co);
 int mmft_u16_conv3x3_wgrad(const void* x, int rgb_f32, const void* dy, float* dw, int accumulate, int N, int H, int W, int Ci,
                            int Co, float* workspace, long long workspace_bytes, int device, void* stream);
 /* BatchNorm2d in train mode, per-image statistics (src/Unet.py:17,20; one image per call in src/train.py:465) + ReLU
@@ -546,12 +575,16 @@ int mmft_u16_convt_fwd(const void* x, const void* wpk, const float* bias, void* 
                        void* stream);
 int mmft_u16_convt_dgrad(const void* g, int ldu, const void* wpk_t, void* dx, int N, int h, int w, int Ci, int device, void* stream);
 long long mmft_u16_convt_wgrad_workspace_bytes(int N, int h, int w, int Ci);
+/* slabs of 4 Co Ci + 4 Co floats: [weights in the parameter's order | bias column sums per (a, b)]; dw == NULL: see above */
+int mmft_u16_convt_wgrad_slabs(int N, int h, int w);
 int mmft_u16_convt_wgrad(const void* x, const void* g, int ldu, float* dw, float* db, int accumulate, int N, int h, int w, int Ci,
                          float* workspace, long long workspace_bytes, int device, void* stream);
 /* OutConv (src/Unet.py:71-82) on a bf16 input of 16 channels; out / gout fp32 */
 int mmft_u16_outconv_fwd(const void* x, const float* w, const float* bias, float* out, int N, int H, int W, int mode, int device,
                          void* stream);
 long long mmft_u16_outconv_bwd_workspace_bytes(int N, int H, int W);
+/* slabs of 17 floats: [dw[16] | db]; dw == NULL: see above */
+int mmft_u16_outconv_bwd_slabs(int N, int H, int W);
 int mmft_u16_outconv_bwd(const void* x, const float* w, const float* bias, const float* gout, void* dx, float* dw, float* db,
                          int accumulate, int N, int H, int W, int mode, float* workspace, long long workspace_bytes, int device,
                          void* stream);

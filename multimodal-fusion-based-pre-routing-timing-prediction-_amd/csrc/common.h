@@ -10,6 +10,7 @@
 namespace mmft {
 
 void set_error(const char* fmt, ...);
+int math_mode();            // MMFT_MATH_F32 / MMFT_MATH_BF16 (linear.hip)
 
 struct DeviceGuard {
   int prev;
@@ -113,5 +114,14 @@ inline int ew_grid(long long work_items, int block = 256) {
   if (g > 256 * 8) g = 256 * 8;
   return (int)g;
 }
+
+// slab reductions (linear.hip): partial results written by the workgroups of a split kernel, added in a fixed order
+struct SlabSeg {
+  const float* slabs;
+  float* out;
+  long long stride;      // floats between slabs
+  int splits, elems, fold, accumulate;
+};
+int launch_slab_reduce_batch(const SlabSeg* segs, int n, hipStream_t st);
 
 }  // namespace mmft

@@ -49,6 +49,20 @@ __device__ __forceinline__ fg_f32x4 fold_net_value(const FoldSrc& s, int u, int 
   return fg_finish_net(acc, fg_ld4(s.pre + (long long)u * s.ld + c), s.relu);
 }
 
+// Reverse sweep, one cell consumer c of a net row: g += DA[c] * exp(h - LSE[c]) * (1 + h - A[c])   (d a_c / d m of the
+// softmax-weighted sum, src/model.py:113-116).  Every operation is rounded on its own (no fused multiply-add), so that the
+// kernels that share this term - level_bwd_pull (graph.hip) and the pair kernel (mlp2_bf16.hip) - agree bit for bit
+// whatever the compiler would contract around them.  FAST (bf16 math mode): the exponential is the hardware's
+// v_exp_f32(x log2 e) - two instructions instead of ~15, relative error ~|x| 6e-8 on a factor in (0, 1]; the reverse sweep's
+// sink phase is bound by VALU issue, not by memory, and 16 of these per lane per sink were most of it.
+template <bool FAST>
+__device__ __forceinline__ float cell_consumer_term(float g, float da, float hv, float lse, float a) {
+  const float x = __fsub_rn(hv, lse);
+  const float ex = FAST ? __builtin_amdgcn_exp2f(__fmul_rn(x, 1.44269504088896340736f)) : expf(x);
+  const float w = __fmul_rn(da, ex);
+  return __fadd_rn(g, __fmul_rn(w, __fsub_rn(__fadd_rn(1.0f, hv), a)));
+}
+
 struct SoftAcc {
   fg_f32x4 mx, s, acc;
   __device__ __forceinline__ void init() {

@@ -153,8 +153,9 @@ __global__ void __launch_bounds__(256) bcast_row_kernel(const float* __restrict_
 // Stage 1: D[c] = sum of gout over the batch rows whose path has a run ENDING at cell c, minus those with a run STARTING
 // at c + 1 inside the block (`code` >= 0: path id, run end; < 0: path id = -code - 1, run start).  Entry lane j owns the
 // cells [j S/J, (j+1) S/J) and walks their boundary lists with four index -> batch-row -> gradient-row chains in flight;
-// D stays in LDS.  Stage 2 (lane 0's channel groups): suffix sums of D give dg[c] = d loss / d(f[c] wT[c]); emit the
-// design's dwT slab (f dg) and df[c] = <dg, wT[c]> (wave-shuffle reduction over the GROUPS lanes).  Fixed orders.
+// D stays in LDS.  Stage 2 (every lane: local suffix sums of its cells + the later lanes' totals): suffix sums of D give
+// dg[c] = d loss / d(f[c] wT[c]); emit the design's dwT slab (f dg) and df[c] = <dg, wT[c]> (wave-shuffle reduction over the
+// GROUPS lanes).  Fixed orders.
 constexpr int MFB_THREADS = 512;      // 16 entry lanes x 32 channel groups at Dout = 128: 4 cells per lane (256: 246 us, 512: 192 us, 1024: 231 us)
 template <int GROUPS>
 __global__ void __launch_bounds__(MFB_THREADS) masked_fc_bwd_runs_kernel(const int* __restrict__ bptr, const int* __restrict__ bcode,
@@ -174,9 +175,22 @@ __global__ void __launch_bounds__(MFB_THREADS) masked_fc_bwd_runs_kernel(const i
     return sum;
   };
   const int cpl = S / J;
+  // the boundary-list pointers of the lane's cells in one go (they are consecutive): the cells' chains start together
+  int eb[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) eb[i] = (cpl <= 8 && i <= cpl) ? bptr[cell0 + j * cpl + i] : 0;
   for (int y = j * cpl; y < (j + 1) * cpl; ++y) {
     f32x4 acc = z;
-    int e = bptr[cell0 + y], e1 = bptr[cell0 + y + 1];
+    int e, e1;
+    if (cpl <= 8) {
+      e = e1 = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i == y - j * cpl) { e = eb[i]; e1 = eb[i + 1]; }
+    } else {
+      e = bptr[cell0 + y];
+      e1 = bptr[cell0 + y + 1];
+    }
     for (; e + 4 <= e1; e += 4) {
       int k0 = bcode[e], k1 = bcode[e + 1], k2 = bcode[e + 2], k3 = bcode[e + 3];
       int t0 = first[k0 >= 0 ? k0 : -k0 - 1], t1 = first[k1 >= 0 ? k1 : -k1 - 1];
@@ -201,13 +215,22 @@ __global__ void __launch_bounds__(MFB_THREADS) masked_fc_bwd_runs_kernel(const i
     }
     *reinterpret_cast<f32x4*>(dl + y * Dout + c4 * 4) = acc;
   }
+  // Stage 2: suffix sums over the block's cells, all entry lanes at work: lane j turns its own cells into local suffix sums,
+  // the lanes' totals are added from the block's end (fixed order), and every lane finishes its cells.
+  __shared__ f32x4 tot[MFB_THREADS];
+  f32x4 run = z;
+  for (int y = (j + 1) * cpl - 1; y >= j * cpl; --y) {
+    run += *reinterpret_cast<const f32x4*>(dl + y * Dout + c4 * 4);
+    *reinterpret_cast<f32x4*>(dl + y * Dout + c4 * 4) = run;
+  }
+  tot[threadIdx.x] = run;
   __syncthreads();
-  if (j != 0) return;
-  f32x4 acc = z;
-  for (int y = S - 1; y >= 0; --y) {
+  f32x4 off = z;
+  for (int jj = J - 1; jj > j; --jj) off += tot[jj * GROUPS + c4];
+  for (int y = (j + 1) * cpl - 1; y >= j * cpl; --y) {
     const long long cell = cell0 + y;
-    acc += *reinterpret_cast<const f32x4*>(dl + y * Dout + c4 * 4);
-    f32x4 w = *reinterpret_cast<const f32x4*>(wT + ((long long)blk * S + y) * Dout + c4 * 4);
+    const f32x4 acc = *reinterpret_cast<const f32x4*>(dl + y * Dout + c4 * 4) + off;
+    const f32x4 w = *reinterpret_cast<const f32x4*>(wT + ((long long)blk * S + y) * Dout + c4 * 4);
     *reinterpret_cast<f32x4*>(dwT + cell * Dout + c4 * 4) = acc * f[cell];
     float d = acc.x * w.x + acc.y * w.y + acc.z * w.z + acc.w * w.w;
 #pragma unroll

@@ -86,6 +86,8 @@ __global__ void __launch_bounds__(256) seg_mean_fwd_kernel(const float* __restri
   }
 }
 
+// FAST: the hardware exponential in the cell-consumer term (bf16 math mode, see fold_gather.h)
+template <bool FAST>
 __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
     float* __restrict__ G, const float* __restrict__ h, long long ld, const int* __restrict__ rows, int row0, int n,
     int D, const int* __restrict__ on_ptr, const int* __restrict__ on_idx, const float* __restrict__ on_w,
@@ -129,7 +131,7 @@ __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
           long long wo = (long long)oc_idx[e] * ld + c;
           f32x4 da = ld4(DA + wo), a = ld4(A + wo), l = ld4(LSE + wo);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) g[j] += da[j] * expf(hv[j] - l[j]) * (1.0f + hv[j] - a[j]);
+          for (int j = 0; j < 4; ++j) g[j] = cell_consumer_term<FAST>(g[j], da[j], hv[j], l[j], a[j]);
         }
         part[tg][c >> 2] = g;
       }
@@ -186,8 +188,10 @@ __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
       const bool k0 = !active || active[w0], k1 = !active || active[w1];    // outside the cone: contributes exactly zero
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        g[j] += k0 ? da0[j] * expf(hv[j] - l0[j]) * (1.0f + hv[j] - a0[j]) : 0.f;
-        g[j] += k1 ? da1[j] * expf(hv[j] - l1[j]) * (1.0f + hv[j] - a1[j]) : 0.f;
+        const float t0 = cell_consumer_term<FAST>(g[j], da0[j], hv[j], l0[j], a0[j]);
+        g[j] = k0 ? t0 : g[j];
+        const float t1 = cell_consumer_term<FAST>(g[j], da1[j], hv[j], l1[j], a1[j]);
+        g[j] = k1 ? t1 : g[j];
       }
     }
     for (; e < e1; ++e) {
@@ -196,7 +200,7 @@ __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
       long long wo = (long long)w * ld + c;
       f32x4 da = ld4(DA + wo), a = ld4(A + wo), l = ld4(LSE + wo);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) g[j] += da[j] * expf(hv[j] - l[j]) * (1.0f + hv[j] - a[j]);
+      for (int j = 0; j < 4; ++j) g[j] = cell_consumer_term<FAST>(g[j], da[j], hv[j], l[j], a[j]);
     }
     if (relu) {
 #pragma unroll
@@ -689,10 +693,15 @@ int mmft_level_bwd_pull(float* G, const float* h, long long ld, const int* rows,
   DeviceGuard dg(device);
   const int light = node_grid(n, D);
   const int hb = nheavy < 1024 ? nheavy : 1024;
-  MMFT_LAUNCH("level_bwd_pull_kernel", 0.0, alg_bytes > 0 ? (double)alg_bytes : 3.0 * 4.0 * n * D, level_bwd_pull_kernel,
-              dim3(light + hb), dim3(256), (hipStream_t)stream, G, h, ld, rows, row0, n, D, out_net_indptr,
-              out_net_indices, out_net_weight, out_cell_indptr, out_cell_indices, A, LSE, DA, relu, own_mask,
-              nheavy ? heavy_rows : nullptr, nheavy, light, heavy_thresh, active);
+  const double by = alg_bytes > 0 ? (double)alg_bytes : 3.0 * 4.0 * n * D;
+  if (math_mode() == MMFT_MATH_BF16)
+    MMFT_LAUNCH("level_bwd_pull_kernel", 0.0, by, level_bwd_pull_kernel<true>, dim3(light + hb), dim3(256), (hipStream_t)stream, G, h, ld,
+                rows, row0, n, D, out_net_indptr, out_net_indices, out_net_weight, out_cell_indptr, out_cell_indices, A, LSE, DA, relu,
+                own_mask, nheavy ? heavy_rows : nullptr, nheavy, light, heavy_thresh, active);
+  else
+    MMFT_LAUNCH("level_bwd_pull_kernel", 0.0, by, level_bwd_pull_kernel<false>, dim3(light + hb), dim3(256), (hipStream_t)stream, G, h, ld,
+                rows, row0, n, D, out_net_indptr, out_net_indices, out_net_weight, out_cell_indptr, out_cell_indices, A, LSE, DA, relu,
+                own_mask, nheavy ? heavy_rows : nullptr, nheavy, light, heavy_thresh, active);
   return check_launch("level_bwd_pull");
 }
 

@@ -118,6 +118,73 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
   }
 }
 
+// Several slab reductions in ONE launch (the U-Net's 18 weight-gradient reductions of a step: each of them alone is a
+// handful of workgroups walking a few hundred slabs - 4-10 us of latency per launch, 50 us for the serial forms they
+// replace - and nothing downstream needs any of them before the optimizer).  out[i] (+)= sum over slabs z (and over `fold`
+// consecutive segments of `elems` floats inside a slab: the four (a, b) column sums of a transposed convolution's bias)
+// of slabs[z * stride + f * elems + i]; per result the same 16 z-lanes / fixed LDS order as slab_reduce_kernel.
+constexpr int SLAB_BATCH_MAX = 24;
+struct SlabBatchDesc {
+  const float* slabs;
+  float* out;
+  long long stride;
+  int splits, elems, fold, accumulate, blk0, vec;
+};
+struct SlabBatchArgs {
+  SlabBatchDesc d[SLAB_BATCH_MAX];
+  int n;
+};
+
+__global__ void __launch_bounds__(256) slab_reduce_batch_kernel(SlabBatchArgs a) {
+  __shared__ float part[16][65];
+  int k = 0;
+#pragma unroll 1
+  for (int i = 1; i < a.n; ++i)
+    if ((int)blockIdx.x >= a.d[i].blk0) k = i;
+  const SlabBatchDesc& d = a.d[k];
+  const int zl = threadIdx.x >> 4, cg = threadIdx.x & 15, vec = d.vec ? 4 : 1;
+  const long long i0 = ((long long)((int)blockIdx.x - d.blk0) * 16 + cg) * vec;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i0 < d.elems) {
+    const long long zs = 16 * d.stride;
+    for (int f = 0; f < d.fold; ++f) {
+      const float* q = d.slabs + (long long)zl * d.stride + (long long)f * d.elems + i0;
+      int z = zl;
+      if (d.vec) {
+        for (; z + 48 < d.splits; z += 64, q += 4 * zs) {                 // four slabs of this lane in flight
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(q), v1 = *reinterpret_cast<const f32x4*>(q + zs);
+          const f32x4 v2 = *reinterpret_cast<const f32x4*>(q + 2 * zs), v3 = *reinterpret_cast<const f32x4*>(q + 3 * zs);
+          acc[0] += v0.x; acc[1] += v0.y; acc[2] += v0.z; acc[3] += v0.w;
+          acc[0] += v1.x; acc[1] += v1.y; acc[2] += v1.z; acc[3] += v1.w;
+          acc[0] += v2.x; acc[1] += v2.y; acc[2] += v2.z; acc[3] += v2.w;
+          acc[0] += v3.x; acc[1] += v3.y; acc[2] += v3.z; acc[3] += v3.w;
+        }
+        for (; z < d.splits; z += 16, q += zs) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(q);
+          acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+        }
+      } else {
+        for (; z + 48 < d.splits; z += 64, q += 4 * zs) {
+          const float v0 = q[0], v1 = q[zs], v2 = q[2 * zs], v3 = q[3 * zs];
+          acc[0] += v0; acc[0] += v1; acc[0] += v2; acc[0] += v3;
+        }
+        for (; z < d.splits; z += 16, q += zs) acc[0] += q[0];
+      }
+    }
+  }
+  for (int j = 0; j < vec; ++j) part[zl][cg * vec + j] = acc[j];
+  __syncthreads();
+  if ((int)threadIdx.x < 16 * vec) {
+    const long long i = (long long)((int)blockIdx.x - d.blk0) * 16 * vec + threadIdx.x;
+    if (i < d.elems) {
+      float s = d.accumulate ? d.out[i] : 0.f;
+#pragma unroll
+      for (int z = 0; z < 16; ++z) s += part[z][threadIdx.x];
+      d.out[i] = s;
+    }
+  }
+}
+
 // slab z starts at slabs + z * stride (stride >= elems: slabs that carry more than one result, e.g. [weights | column sums])
 int launch_slab_reduce_strided(const float* slabs, int splits, long long stride, long long elems, float* out, int accumulate,
                                hipStream_t st) {
@@ -134,6 +201,40 @@ int launch_slab_reduce_strided(const float* slabs, int splits, long long stride,
 
 int launch_slab_reduce(const float* slabs, int splits, long long elems, float* out, int accumulate, hipStream_t st) {
   return launch_slab_reduce_strided(slabs, splits, elems, elems, out, accumulate, st);
+}
+
+// n <= SLAB_BATCH_MAX reductions in one launch (see slab_reduce_batch_kernel); per result the summation order of
+// slab_reduce_kernel, so a result does not depend on which of the two launchers produced it
+int launch_slab_reduce_batch(const SlabSeg* segs, int n, hipStream_t st) {
+  if (n <= 0) return MMFT_OK;
+  if (n > SLAB_BATCH_MAX) {
+    set_error("slab_reduce_batch: at most %d reductions per launch (got %d)", SLAB_BATCH_MAX, n);
+    return MMFT_ERR_BAD_ARG;
+  }
+  SlabBatchArgs a;
+  a.n = n;
+  int blocks = 0;
+  double by = 0.0;
+  for (int i = 0; i < n; ++i) {
+    SlabBatchDesc& d = a.d[i];
+    d.slabs = segs[i].slabs;
+    d.out = segs[i].out;
+    d.stride = segs[i].stride;
+    d.splits = segs[i].splits;
+    d.elems = segs[i].elems;
+    d.fold = segs[i].fold;
+    d.accumulate = segs[i].accumulate ? 1 : 0;
+    if (!(d.slabs && d.out && d.splits > 0 && d.elems > 0 && d.fold >= 1 && d.stride >= (long long)d.elems * d.fold)) {
+      set_error("slab_reduce_batch: bad descriptor %d", i);
+      return MMFT_ERR_BAD_ARG;
+    }
+    d.vec = (d.elems % 4 == 0 && d.stride % 4 == 0 && aligned16(d.slabs) && aligned16(d.out)) ? 1 : 0;
+    d.blk0 = blocks;
+    blocks += cdiv(d.elems, d.vec ? 64 : 16);
+    by += 4.0 * ((double)d.splits * d.fold + 1.0) * d.elems;
+  }
+  MMFT_LAUNCH("slab_reduce_batch_kernel", 0.0, by, slab_reduce_batch_kernel, dim3(blocks), dim3(256), st, a);
+  return check_launch("slab_reduce_batch");
 }
 
 // ---------------------------------------------------------------- column sums (bias gradients)
@@ -384,6 +485,22 @@ int mmft_linear_wgrad_bias(const float* g, const int* gidx, long long ldg, const
   MMFT_REQUIRE(db, "linear_wgrad_bias: null bias-gradient pointer");
   return wgrad_impl(g, gidx, ldg, x, xidx, ldx, dw, lddw, db, rows, out, in, accumulate, workspace, workspace_bytes,
                     device, stream);
+}
+
+/* n <= 24 slab reductions in one launch.  table (HOST memory) = n rows of seven 64-bit integers: slabs (device pointer), out
+ * (device pointer), splits, stride (floats between slabs), elems, fold (segments of `elems` floats added together, >= 1),
+ * accumulate.  Each result is summed in a fixed order (bitwise reproducible). */
+int mmft_slab_reduce_batch(const long long* table, int n, int device, void* stream) {
+  MMFT_REQUIRE(table && n >= 0 && n <= SLAB_BATCH_MAX, "slab_reduce_batch: 0 .. %d reductions per launch", SLAB_BATCH_MAX);
+  if (n == 0) return MMFT_OK;
+  SlabSeg segs[SLAB_BATCH_MAX];
+  for (int i = 0; i < n; ++i) {
+    const long long* t = table + 7 * i;
+    segs[i] = SlabSeg{reinterpret_cast<const float*>(t[0]), reinterpret_cast<float*>(t[1]), t[3], (int)t[2], (int)t[4], (int)t[5],
+                      t[6] ? 1 : 0};
+  }
+  DeviceGuard dg(device);
+  return launch_slab_reduce_batch(segs, n, (hipStream_t)stream);
 }
 
 long long mmft_colsum_workspace_bytes(int rows, int cols) { return (long long)colsum_blocks(rows) * cols * 4; }

@@ -467,6 +467,269 @@ __global__ void __launch_bounds__(512) level_fwd_slots_kernel(LevelSlotsArgs a) 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Reverse sweep of one (cell level l, net level l + 1) PAIR in ONE launch (three before: pull of the net level, pull of
+// the cell level, fc_cell_neigh's backward):
+//   net rows w of level l + 1 (the SINKS of the level-l drivers):
+//       G[w] = relu'(h[w]) (own[w] ? G[w] : 0  +  sum over the cell consumers c of w, in edge order, of
+//                           DA[c] exp(h[w] - LSE[c]) (1 + h[w] - A[c]))                         (src/model.py:113-116 reversed)
+//   cell rows v of level l (the DRIVERS):
+//       G[v] = relu'(h[v]) (own[v] ? G[v] : 0  +  sum over v's sinks w, in edge order, of G[w])    (src/model.py:186-187: mean over
+//                                                                                                 ONE in-edge, weight 1)
+//       DA[v] = ((G[v] W2g) * relu'(HN[v])) W1g,  DHN[v] kept for the batched weight gradients   (src/model.py:138-146)
+// Precondition (checked on the host, PinGraph.level_bwd_pairs): the level-l rows are a contiguous id range whose out-net
+// edge list, read in CSR order, IS the id range of level l + 1 - the sinks of one driver are consecutive ids and the
+// drivers' sink runs follow each other.  A workgroup then owns <= 32 consecutive drivers (a static tile table) and with them
+// one contiguous run of sinks: thread group g (32 lanes x 4 channels) takes the sinks g, g + 16, .. of the run (the consumers
+// come from a static slot table int32[N][4], so the chain is slots -> rows; the next sink's slots / h / own row are
+// requested before the current one's rows are consumed), parks the finished sink rows in LDS and the driver's thread group
+// adds its own run in edge order - no driver walks its sinks' dependent loads in series (the form that made the earlier
+// driver-side fold 5x slower than two pulls), no float atomics, and for such tiles the same additions in the same order as
+// level_bwd_pull: bitwise equal (tested).  The finished driver rows go to LDS as bf16 and through the MFMA phases of the level
+// MLP (one or two 16-row blocks).
+// HEAVY drivers (more sinks than a tile's target: drivers of high-fanout nets) would leave their workgroup walking hundreds
+// of sinks while the rest of the card has finished; their sink run is cut into PARTS (16 sinks), one workgroup each.  A part
+// finishes its sinks, writes the partial sum of their rows (in edge order) to scratch and bumps a per-driver counter; the
+// workgroup that arrives last adds the partial sums IN PART ORDER (whichever workgroup that is: the result does not depend on
+// the arrival order), finishes the driver's row and runs the MLP phases for it.  Nobody waits for anybody.
+struct LevelBwdPairArgs {
+  float* G;
+  const float* h;
+  const float* A;
+  const float* LSE;
+  float* DA;
+  long long ld;
+  const unsigned char* own;
+  const int* tiles;            // [gridDim.x][8]: first driver id, driver count (<= 32), part, parts (0 = not a heavy driver),
+                               // first scratch row of the driver's parts, counter index, first / end out-net CSR position of
+                               // the tile's sinks
+  const int* on_ptr;           // out-net CSR row pointers
+  int sink_shift;              // sink id = CSR position + sink_shift
+  const int* cslots;           // [N][4] cell consumers of a net row in out-edge order, -1 = none; slot 3 <= -2: more than four,
+                               // the fourth and later ones are read from the out-cell CSR at position -2 - slot
+  const int* oc_ptr;
+  const int* oc_idx;
+  float* scratch;              // [rows][128] partial sums of heavy drivers' parts
+  int* counters;               // one per heavy driver of the level, zero between launches
+  int relu, has_mlp;
+  const unsigned short* w1;    // bf16 [256][128] = W2g^T   (hidden gradient = G . W2g)
+  const unsigned short* w2;    // bf16 [128][256] = W1g^T
+  const float* mask;           // HN
+  long long ldmask;
+  float* hid_out;              // DHN (optional)
+  long long ldhid;
+};
+
+__global__ void __launch_bounds__(512) level_bwd_pair_kernel(LevelBwdPairArgs a) {
+  constexpr int BM = 32, SC = 32, SGP = L2_K1 + 4;
+  __shared__ __attribute__((aligned(16))) float sg[SC * SGP];
+  __shared__ __attribute__((aligned(16))) unsigned short xs[BM * L2_XS];
+  __shared__ __attribute__((aligned(16))) unsigned short hs[BM * L2_HS];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int gr = tid >> 5, gc = (tid & 31) * 4;
+  const int4 t0 = *reinterpret_cast<const int4*>(a.tiles + 8 * (long long)blockIdx.x);
+  const int4 t1 = *reinterpret_cast<const int4*>(a.tiles + 8 * (long long)blockIdx.x + 4);
+  const int v0 = t0.x, nd = t0.y, part = t0.z, parts = t0.w, sbase = t1.x, cidx = t1.y;
+  const int e0 = t1.z, e1 = t1.w;                          // the tile's sinks: known without a look at the CSR
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  // ---- this thread group's drivers gr and gr + 16: their sink runs, own-row gradients, forward values
+  int ps[2] = {0, 0}, pe[2] = {0, 0};
+  f32x4 acc[2] = {zero, zero}, hv[2] = {zero, zero};
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const int v = v0 + gr + 16 * d;
+    if (gr + 16 * d < nd) {
+      ps[d] = a.on_ptr[v];
+      pe[d] = a.on_ptr[v + 1];
+      hv[d] = *reinterpret_cast<const f32x4*>(a.h + (long long)v * a.ld + gc);
+      const bool mine_v = (!a.own || a.own[v]) && !parts;
+      acc[d] = *reinterpret_cast<const f32x4*>(a.G + (long long)v * a.ld + gc);     // dropped by a select when there is none
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[d][j] = mine_v ? acc[d][j] : 0.f;
+    }
+  }
+  // ---- the tile's sinks, 32 at a time (a tile of whole drivers holds at most 32, a part of a heavy driver 16)
+  for (int c0 = e0; c0 < e1; c0 += SC) {
+    const int cend = c0 + SC < e1 ? c0 + SC : e1;
+    int e = c0 + gr;
+    // stage 1 of a sink: its slots, forward value, own-row gradient (loaded in any case and dropped by a select: a
+    // conditional load would split the request phase into basic blocks, each waiting for its own loads)
+    int4 cs = {-1, -1, -1, -1};
+    f32x4 hw = zero, gw = zero;
+    unsigned char mine = 0;
+    if (e < cend) {
+      const int w = e + a.sink_shift;
+      cs = *reinterpret_cast<const int4*>(a.cslots + (long long)w * 4);
+      hw = *reinterpret_cast<const f32x4*>(a.h + (long long)w * a.ld + gc);
+      mine = a.own ? a.own[w] : (unsigned char)1;
+      gw = *reinterpret_cast<const f32x4*>(a.G + (long long)w * a.ld + gc);
+    }
+#pragma unroll 1
+    for (; e < cend; e += 16) {
+      const int w = e + a.sink_shift;
+      // stage 2: the four slots' rows requested together (a missing one repeats a row already asked for and is dropped)
+      const int c[4] = {cs.x, cs.y, cs.z, cs.w};
+      const int c0row = c[0] >= 0 ? c[0] : w;
+      f32x4 da[4], aa[4], ll[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long long o = (long long)(c[k] >= 0 ? c[k] : c0row) * a.ld + gc;
+        da[k] = *reinterpret_cast<const f32x4*>(a.DA + o);
+        aa[k] = *reinterpret_cast<const f32x4*>(a.A + o);
+        ll[k] = *reinterpret_cast<const f32x4*>(a.LSE + o);
+      }
+      f32x4 g = gw;
+      const f32x4 hcur = hw;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = mine ? g[j] : 0.f;
+      // stage 1 of the group's next sink, in flight while this one's rows arrive and are consumed
+      const int en = e + 16;
+      if (en < cend) {
+        const int wn = en + a.sink_shift;
+        cs = *reinterpret_cast<const int4*>(a.cslots + (long long)wn * 4);
+        hw = *reinterpret_cast<const f32x4*>(a.h + (long long)wn * a.ld + gc);
+        mine = a.own ? a.own[wn] : (unsigned char)1;
+        gw = *reinterpret_cast<const f32x4*>(a.G + (long long)wn * a.ld + gc);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        // the term is ~15 VALU instructions per channel: a slot neither of the wave's two sinks uses is skipped altogether
+        if (!__builtin_amdgcn_ballot_w64(c[k] >= 0)) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = c[k] >= 0 ? cell_consumer_term<true>(g[j], da[k][j], hcur[j], ll[k][j], aa[k][j]) : g[j];
+      }
+      if (c[3] <= -2) {
+        // more than four consumers (a few percent of the pins): slot 3 holds -2 - (CSR position of the fourth one)
+        const int x1 = a.oc_ptr[w + 1];
+        for (int x = -2 - c[3]; x < x1; ++x) {
+          const long long o = (long long)a.oc_idx[x] * a.ld + gc;
+          const f32x4 d2 = *reinterpret_cast<const f32x4*>(a.DA + o), a2 = *reinterpret_cast<const f32x4*>(a.A + o),
+                      l2 = *reinterpret_cast<const f32x4*>(a.LSE + o);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) g[j] = cell_consumer_term<true>(g[j], d2[j], hcur[j], l2[j], a2[j]);
+        }
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = hcur[j] > 0.f ? g[j] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(a.G + (long long)w * a.ld + gc) = g;
+      *reinterpret_cast<f32x4*>(sg + (e - c0) * SGP + gc) = g;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int lo = ps[d] > c0 ? ps[d] : c0, hi = pe[d] < cend ? pe[d] : cend;
+      for (int x = lo; x < hi; ++x) acc[d] += *reinterpret_cast<const f32x4*>(sg + (x - c0) * SGP + gc);
+    }
+    __syncthreads();
+  }
+  if (parts) {
+    // ---- heavy driver: publish this part's partial sum; the last part to arrive adds all of them in part order
+    if (gr == 0) {
+      float* p = a.scratch + (long long)(sbase + part) * L2_K1 + gc;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) __hip_atomic_store(p + j, acc[0][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // the partial sum is visible before the counter moves
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const int old = __hip_atomic_fetch_add(a.counters + cidx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = old == parts - 1;
+      if (old == parts - 1) __hip_atomic_store(a.counters + cidx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next step
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // ... and the other parts' sums are read after it was seen full
+    if (gr == 0) {
+      acc[0] = zero;
+      if (!a.own || a.own[v0]) acc[0] = *reinterpret_cast<const f32x4*>(a.G + (long long)v0 * a.ld + gc);
+      for (int i = 0; i < parts; ++i) {
+        const float* p = a.scratch + (long long)(sbase + i) * L2_K1 + gc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[0][j] += __hip_atomic_load(p + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  // ---- the drivers' rows
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    if (a.relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[d][j] = hv[d][j] > 0.f ? acc[d][j] : 0.f;
+    }
+    if (gr + 16 * d < nd) *reinterpret_cast<f32x4*>(a.G + (long long)(v0 + gr + 16 * d) * a.ld + gc) = acc[d];
+  }
+  if (!a.has_mlp) return;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const unsigned lo = pack_bf16(acc[d].x, acc[d].y), hi = pack_bf16(acc[d].z, acc[d].w);       // rows >= nd hold zeros
+    *reinterpret_cast<unsigned long long*>(xs + (gr + 16 * d) * L2_XS + gc) = ((unsigned long long)hi << 32) | lo;
+  }
+  const bool two = nd > 16;                                  // block-uniform: the second 16-row block holds drivers
+  bf16x8 w1f[2][4], w2f[8];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      w1f[j][ks] = *reinterpret_cast<const bf16x8*>(a.w1 + (long long)(wave * 32 + j * 16 + r16) * L2_K1 + ks * 32 + q * 8);
+  // the ReLU mask of the hidden rows
+  f32x4 mk[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      mk[i][j] = zero;
+      if (r16 + 16 * i < nd)
+        mk[i][j] = *reinterpret_cast<const f32x4*>(a.mask + (long long)(v0 + r16 + 16 * i) * a.ldmask + wave * 32 + j * 16 + q * 4);
+    }
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+    w2f[ks] = *reinterpret_cast<const bf16x8*>(a.w2 + (long long)(wave * 16 + r16) * L2_HD + ks * 32 + q * 8);
+  __syncthreads();
+  // ---- hidden gradient = (G . W2g) * relu'(HN), DA = hidden gradient . W1g: the MFMA phases of mlp2_rows_bf16_kernel
+  f32x4 acc1[2][2] = {{zero, zero}, {zero, zero}};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i == 1 && !two) continue;
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xs + (i * 16 + r16) * L2_XS + ks * 32 + q * 8);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[j][ks], xf, acc1[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (i == 1 && !two) continue;
+    const int row = r16 + 16 * i;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int nn = wave * 32 + j * 16 + q * 4;
+      f32x4 hvv = acc1[i][j];
+      hvv.x = mk[i][j].x > 0.f ? hvv.x : 0.f; hvv.y = mk[i][j].y > 0.f ? hvv.y : 0.f;
+      hvv.z = mk[i][j].z > 0.f ? hvv.z : 0.f; hvv.w = mk[i][j].w > 0.f ? hvv.w : 0.f;
+      const unsigned lo = pack_bf16(hvv.x, hvv.y), hi = pack_bf16(hvv.z, hvv.w);
+      *reinterpret_cast<unsigned long long*>(hs + row * L2_HS + nn) = ((unsigned long long)hi << 32) | lo;
+      if (a.hid_out && row < nd) *reinterpret_cast<f32x4*>(a.hid_out + (long long)(v0 + row) * a.ldhid + nn) = hvv;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (i == 1 && !two) continue;
+    f32x4 acc2 = zero;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hs + (i * 16 + r16) * L2_HS + ks * 32 + q * 8);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[ks], hf, acc2, 0, 0, 0);
+    }
+    if (r16 + 16 * i < nd) *reinterpret_cast<f32x4*>(a.DA + (long long)(v0 + r16 + 16 * i) * a.ld + wave * 16 + q * 4) = acc2;
+  }
+}
+
 // dst[r][c] (bf16) = src[r][c], or with transpose dst[c][r] = src[r][c]   (R x C fp32, row stride ld)
 __global__ void __launch_bounds__(256) pack_bf16_kernel(const float* __restrict__ src, long long ld, int R, int C,
                                                         unsigned short* __restrict__ dst, int transpose) {
@@ -567,4 +830,34 @@ extern "C" int mmft_level_fwd_slots(float* h, const float* pre, long long ld, in
   MMFT_LAUNCH("level_fwd_slots_kernel", fl, alg_bytes > 0 ? (double)alg_bytes : 0.0, level_fwd_slots_kernel,
               dim3(tiles > net_tiles ? tiles : net_tiles), dim3(512), (hipStream_t)stream, a);
   return check_launch("level_fwd_slots");
+}
+
+/* Reverse sweep of one (cell level l, net level l + 1) pair, see level_bwd_pair_kernel: tiles int32[ntiles][8] (first driver id,
+ * count <= 16, part, parts, first scratch row, counter index, first / end CSR position of the tile's sinks) cover the level-l id range; the sink of out-net CSR position
+ * e is row e + sink_shift; cslots int32[N][4]; scratch (fp32 [scratch_rows][128]) and counters (int32, zero before the first
+ * call, left zero) serve the heavy drivers' parts.  has_mlp = 0 (level 0): only the two pulls. */
+extern "C" int mmft_level_bwd_pair(float* G, const float* h, const float* A, const float* LSE, float* DA, long long ld, int D, int N,
+                                   const unsigned char* own_mask, const int* tiles, int ntiles, const int* out_net_indptr,
+                                   int sink_shift, const int* cslots, const int* out_cell_indptr,
+                                   const int* out_cell_indices, float* scratch, int* counters, int relu, int has_mlp,
+                                   const void* w1_bf16, const void* w2_bf16, const float* mask, long long ldmask, float* hid_out,
+                                   long long ldhid, long long alg_bytes, int device, void* stream) {
+  MMFT_REQUIRE(D == L2_K1, "level_bwd_pair: D must be %d", L2_K1);
+  MMFT_REQUIRE(ntiles >= 0 && N > 0, "level_bwd_pair: negative tile count");
+  if (ntiles == 0) return MMFT_OK;
+  MMFT_REQUIRE(G && h && A && LSE && DA && tiles && out_net_indptr && cslots && out_cell_indptr && out_cell_indices && scratch && counters,
+               "level_bwd_pair: null pointer");
+  MMFT_REQUIRE(!has_mlp || (w1_bf16 && w2_bf16 && mask), "level_bwd_pair: the MLP part needs both weight packs and the saved hidden rows");
+  MMFT_REQUIRE(ld >= D && ld % 4 == 0 && aligned16(G) && aligned16(h) && aligned16(A) && aligned16(LSE) && aligned16(DA) &&
+                   aligned16(cslots) && aligned16(tiles) && aligned16(scratch) && (!w1_bf16 || aligned16(w1_bf16)) &&
+                   (!w2_bf16 || aligned16(w2_bf16)) && (!mask || (aligned16(mask) && ldmask % 4 == 0)) &&
+                   (!hid_out || (aligned16(hid_out) && ldhid % 4 == 0)),
+               "level_bwd_pair: operands must be 16-byte aligned");
+  DeviceGuard dg(device);
+  LevelBwdPairArgs a{G, h, A, LSE, DA, ld, own_mask, tiles, out_net_indptr, sink_shift, cslots, out_cell_indptr, out_cell_indices,
+                     scratch, counters, relu, has_mlp, (const unsigned short*)w1_bf16, (const unsigned short*)w2_bf16, mask, ldmask,
+                     hid_out, ldhid};
+  MMFT_LAUNCH("level_bwd_pair_kernel", 0.0, alg_bytes > 0 ? (double)alg_bytes : 0.0, level_bwd_pair_kernel, dim3(ntiles), dim3(512),
+              (hipStream_t)stream, a);
+  return check_launch("level_bwd_pair");
 }

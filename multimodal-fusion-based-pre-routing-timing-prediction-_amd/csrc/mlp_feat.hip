@@ -331,19 +331,6 @@ __global__ void __launch_bounds__(512) mlp2_feat_bwd_kernel(FeatBwdArgs a) {
   }
 }
 
-// out[e] (+)= sum over slabs (fixed order); the four gradients are the four segments of a slab
-__global__ void __launch_bounds__(256) mlp2_feat_reduce_kernel(const float* __restrict__ slabs, int nslab, long long slab, int fin,
-                                                               float* __restrict__ dw1, float* __restrict__ db1,
-                                                               float* __restrict__ dw2, float* __restrict__ db2, int accumulate) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= slab) return;
-  float s = 0.f;
-  for (int b = 0; b < nslab; ++b) s += slabs[(long long)b * slab + e];
-  const long long n1 = (long long)MF_HD * fin, n2 = n1 + MF_HD, n3 = n2 + (long long)MF_D2 * MF_HD;
-  float* dst = e < n1 ? dw1 + e : e < n2 ? db1 + (e - n1) : e < n3 ? dw2 + (e - n2) : db2 + (e - n3);
-  *dst = accumulate ? *dst + s : s;
-}
-
 template <int KS>
 constexpr int feat_bwd_lds() {
   constexpr int BM = 32, KP = KS * 32, XS = KP + 8, GS = MF_D2 + 8, TS = BM + 8;
@@ -411,11 +398,15 @@ extern "C" int mmft_mlp2_feat_bwd_bf16(const float* g, long long ldg, const floa
   int rc = check_launch("mlp2_feat_bwd_bf16");
   if (rc) return rc;
   // The four gradients are the four segments of a slab.  In FlatAdam's gradient buffer they are neighbours in exactly that
-  // order (weight, bias, weight, bias of one MLP), so ONE parallel slab reduction finishes all of them; scattered outputs take
-  // the segment-aware kernel (one thread per element, 62 us at 256 slabs against 9).
+  // order (weight, bias, weight, bias of one MLP), so ONE parallel slab reduction finishes all of them.
   if (db1 == dw1 + (long long)MF_HD * fin && dw2 == db1 + MF_HD && db2 == dw2 + (long long)MF_D2 * MF_HD && aligned16(dw1))
     return launch_slab_reduce(workspace, grid, slab, dw1, accumulate, st);
-  hipLaunchKernelGGL(mlp2_feat_reduce_kernel, dim3(cdiv(slab, 256)), dim3(256), 0, st, workspace, grid, slab, fin, dw1, db1, dw2,
-                     db2, accumulate ? 1 : 0);
-  return check_launch("mlp2_feat_reduce");
+  // scattered outputs: the same four reductions as one batched launch - per element the summation order of the joined form,
+  // so the gradients do not depend on where the caller's (or the allocator's) tensors happen to lie
+  const long long o1 = (long long)MF_HD * fin, o2 = o1 + MF_HD, o3 = o2 + (long long)MF_D2 * MF_HD;
+  const SlabSeg segs[4] = {{workspace, dw1, slab, grid, (int)o1, 1, accumulate ? 1 : 0},
+                           {workspace + o1, db1, slab, grid, MF_HD, 1, accumulate ? 1 : 0},
+                           {workspace + o2, dw2, slab, grid, MF_D2 * MF_HD, 1, accumulate ? 1 : 0},
+                           {workspace + o3, db2, slab, grid, MF_D2, 1, accumulate ? 1 : 0}};
+  return launch_slab_reduce_batch(segs, 4, st);
 }

@@ -541,13 +541,18 @@ long long mmft_u16_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Ci, in
   return (long long)u16_wgrad_grid_x(tiles, gy) * Co * 9 * Ci * 4;
 }
 
+/* number of slabs (Co * 9 * Ci floats each, back to back) the weight-gradient kernel leaves in its workspace */
+int mmft_u16_conv3x3_wgrad_slabs(int N, int H, int W, int Ci, int Co) {
+  return (int)(mmft_u16_conv3x3_wgrad_workspace_bytes(N, H, W, Ci, Co) / ((long long)Co * 9 * Ci * 4));
+}
+
 int mmft_u16_conv3x3_wgrad(const void* x, int rgb_f32, const void* dy, float* dw, int accumulate, int N, int H, int W, int Ci,
                            int Co, float* workspace, long long workspace_bytes, int device, void* stream) {
-  MMFT_REQUIRE(x && dy && dw && N > 0 && H > 0 && W > 0, "u16_conv3x3_wgrad: bad arguments");
+  MMFT_REQUIRE(x && dy && N > 0 && H > 0 && W > 0, "u16_conv3x3_wgrad: bad arguments");
   MMFT_REQUIRE(u16_channels_ok(Co) && (rgb_f32 ? (Ci == 3 && Co == 16) : u16_channels_ok(Ci)),
                "u16_conv3x3_wgrad: channels must be 16 / 32 / 64 / 128 (or the 3 -> 16 RGB layer)");
   MMFT_REQUIRE(workspace && workspace_bytes >= mmft_u16_conv3x3_wgrad_workspace_bytes(N, H, W, Ci, Co) && aligned16(workspace) &&
-                   aligned16(x) && aligned16(dy) && aligned16(dw),
+                   aligned16(x) && aligned16(dy) && (!dw || aligned16(dw)),
                "u16_conv3x3_wgrad: workspace too small or operands not 16-byte aligned");
   DeviceGuard dg(device);
   hipStream_t st = (hipStream_t)stream;
@@ -570,7 +575,7 @@ int mmft_u16_conv3x3_wgrad(const void* x, int rgb_f32, const void* dy, float* dw
   else if (cob == 16) rc = U16_WG(32, 16, false);
   else rc = U16_WG(32, 32, false);
 #undef U16_WG
-  if (rc) return rc;
+  if (rc || !dw) return rc;          // dw == NULL: the slabs stay in `workspace` for mmft_slab_reduce_batch
   return launch_slab_reduce(workspace, gx, (long long)Co * 9 * Ci, dw, accumulate, st);
 }
 

@@ -245,10 +245,13 @@ long long mmft_u16_convt_wgrad_workspace_bytes(int N, int h, int w, int Ci) {
   return (long long)u16_ct_wgrad_grid((long long)N * h * w) * (4LL * Co * Ci + 4 * Co) * 4;
 }
 
+/* slabs of 4 Co Ci + 4 Co floats: [weights in the parameter's order | column sums per (a, b)] */
+int mmft_u16_convt_wgrad_slabs(int N, int h, int w) { return u16_ct_wgrad_grid((long long)N * h * w); }
+
 /* dw: [(a,b,co)][ci] (the parameter's memory order, see Unet.Up); db: [Co] or null */
 int mmft_u16_convt_wgrad(const void* x, const void* g, int ldu, float* dw, float* db, int accumulate, int N, int h, int w, int Ci,
                          float* workspace, long long workspace_bytes, int device, void* stream) {
-  MMFT_REQUIRE(x && g && dw, "u16_convt_wgrad: null pointer");
+  MMFT_REQUIRE(x && g, "u16_convt_wgrad: null pointer");
   U16_CT_CHECK("u16_convt_wgrad")
   MMFT_REQUIRE(workspace && workspace_bytes >= mmft_u16_convt_wgrad_workspace_bytes(N, h, w, Ci), "u16_convt_wgrad: workspace too small");
   DeviceGuard dg(device);
@@ -261,7 +264,7 @@ int mmft_u16_convt_wgrad(const void* x, const void* g, int ldu, float* dw, float
   else if (Ci == 64) MMFT_LAUNCH("u16_convt_wgrad_kernel", fl, by, u16_convt_wgrad_kernel<64>, dim3(grid), dim3(256), st, a);
   else MMFT_LAUNCH("u16_convt_wgrad_kernel", fl, by, u16_convt_wgrad_kernel<32>, dim3(grid), dim3(256), st, a);
   int rc = check_launch("u16_convt_wgrad");
-  if (rc) return rc;
+  if (rc || !dw) return rc;          // dw == NULL: the slabs stay in `workspace` for mmft_slab_reduce_batch
   const long long el = 4LL * Co * Ci + Co;
   hipLaunchKernelGGL(u16_convt_reduce_kernel, dim3((int)((el + 255) / 256)), dim3(256), 0, st, workspace, grid, Co, Ci, dw, db,
                      accumulate ? 1 : 0);

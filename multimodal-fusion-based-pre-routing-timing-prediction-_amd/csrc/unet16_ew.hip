@@ -573,10 +573,13 @@ long long mmft_u16_outconv_bwd_workspace_bytes(int N, int H, int W) {
   return (long long)u16_oc_grid((long long)N * (H / 2) * (W / 32)) * 17 * 4;
 }
 
+/* slabs of 17 floats: [dw[16] | db] */
+int mmft_u16_outconv_bwd_slabs(int N, int H, int W) { return u16_oc_grid((long long)N * (H / 2) * (W / 32)); }
+
 int mmft_u16_outconv_bwd(const void* x, const float* w, const float* bias, const float* gout, void* dx, float* dw, float* db,
                          int accumulate, int N, int H, int W, int mode, float* workspace, long long workspace_bytes, int device,
                          void* stream) {
-  MMFT_REQUIRE(x && w && gout && dx && dw && N > 0 && H % 2 == 0 && W % 32 == 0 && (mode == MMFT_POOL_MAX || mode == MMFT_POOL_AVG) &&
+  MMFT_REQUIRE(x && w && gout && dx && N > 0 && H % 2 == 0 && W % 32 == 0 && (mode == MMFT_POOL_MAX || mode == MMFT_POOL_AVG) &&
                    aligned16(x) && aligned16(dx),
                "u16_outconv_bwd: needs 16 input channels, even H, W %% 32 == 0");
   MMFT_REQUIRE(workspace && workspace_bytes >= mmft_u16_outconv_bwd_workspace_bytes(N, H, W), "u16_outconv_bwd: workspace too small");
@@ -588,7 +591,7 @@ int mmft_u16_outconv_bwd(const void* x, const float* w, const float* bias, const
   MMFT_LAUNCH("u16_outconv_bwd_kernel", 4.0 * N * H * W * 16, 4.0 * N * H * W * 16 + 1.0 * N * H * W, u16_outconv_bwd_kernel, dim3(grid),
               dim3(256), st, a);
   int rc = check_launch("u16_outconv_bwd");
-  if (rc) return rc;
+  if (rc || !dw) return rc;          // dw == NULL: the slabs stay in `workspace` for mmft_slab_reduce_batch
   hipLaunchKernelGGL(u16_outconv_reduce_kernel, dim3(1), dim3(512), 0, st, workspace, grid, dw, db, accumulate ? 1 : 0);
   return check_launch("u16_outconv_reduce");
 }

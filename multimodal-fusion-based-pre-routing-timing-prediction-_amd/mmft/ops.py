@@ -305,6 +305,53 @@ def level_fwd_slots(h, pre, slots, net_driver, net_range, cell_range, A, LSE, w1
              hid_out, hid_out.stride(0), int(relu), _active(active, N), int(alg_bytes), dev, st)
 
 
+def level_bwd_pair(G, h, A, LSE, DA, own, tiles, ntiles, out_net_indptr, sink_shift, cslots, out_cell, scratch, counters, w1p, w2p,
+                   HN, DHN, relu=True,
+                   has_mlp=True, alg_bytes=0):
+    """Reverse sweep of one (cell level, net level above it) pair in one launch (mmft_level_bwd_pair); the tables come from
+    PinGraph.level_bwd_pairs, which checks the layout the kernel assumes."""
+    for t, nm in ((G, 'G'), (h, 'h'), (A, 'A'), (LSE, 'LSE'), (DA, 'DA')):
+        _rows2d(t, nm)
+        if t.shape != h.shape or t.stride(0) != h.stride(0):
+            raise ValueError(f'level_bwd_pair: {nm} must have the layout of h')
+    N = h.shape[0]
+    if h.shape[1] != 128:
+        raise ValueError('level_bwd_pair: D = 128 only')
+    if not (torch.is_tensor(tiles) and tiles.is_cuda and tiles.dtype == torch.int32 and tiles.dim() == 2 and tiles.shape[1] == 8
+            and tiles.is_contiguous() and tiles.shape[0] == ntiles):
+        raise ValueError('level_bwd_pair: tiles must be a contiguous int32 CUDA tensor [ntiles, 8]')
+    _chk(scratch, 'scratch')
+    _chk(counters, 'counters', torch.int32)
+    if scratch.dim() != 2 or scratch.shape[1] != 128 or not scratch.is_contiguous():
+        raise ValueError('level_bwd_pair: scratch must be a contiguous fp32 [rows, 128] tensor')
+    if not (torch.is_tensor(cslots) and cslots.is_cuda and cslots.dtype == torch.int32 and tuple(cslots.shape) == (N, 4)
+            and cslots.is_contiguous()):
+        raise ValueError('level_bwd_pair: cslots must be a contiguous int32 CUDA tensor [N, 4]')
+    _chk(out_net_indptr, 'out_net_indptr', torch.int32)
+    if out_net_indptr.numel() != N + 1:
+        raise ValueError('level_bwd_pair: out_net_indptr must have N + 1 entries')
+    _csr(out_cell[0], out_cell[1], N, 'out_cell')
+    if own is not None:
+        _chk(own, 'own', torch.uint8)
+        if own.numel() != N:
+            raise ValueError('level_bwd_pair: one own-gradient flag per node expected')
+    if has_mlp:
+        for t, nm, shape in ((w1p, 'w1p', (256, 128)), (w2p, 'w2p', (128, 256))):
+            if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.bfloat16 and tuple(t.shape) == shape and t.is_contiguous()):
+                raise ValueError(f'level_bwd_pair: {nm} must be a contiguous bf16 CUDA tensor of shape {shape}')
+        for t, nm in ((HN, 'HN'), (DHN, 'DHN')):
+            if t is None and nm == 'DHN':
+                continue
+            _rows2d(t, nm)
+            if tuple(t.shape) != (N, 256):
+                raise ValueError(f'level_bwd_pair: {nm} must be [N, 256]')
+    dev, st = lib.stream_args(h)
+    lib.call('mmft_level_bwd_pair', G, h, A, LSE, DA, h.stride(0), 128, N, own, tiles, int(ntiles), out_net_indptr, int(sink_shift),
+             cslots, out_cell[0], out_cell[1], scratch, counters, int(relu), int(bool(has_mlp)), w1p if has_mlp else None, w2p if has_mlp else None, HN if has_mlp else None,
+             HN.stride(0) if has_mlp else 0, DHN if has_mlp else None, DHN.stride(0) if (has_mlp and DHN is not None) else 0,
+             int(alg_bytes), dev, st)
+
+
 def mlp2_feat_fusable(fin, HD, D2):
     return 1 <= fin <= 64 and HD == 256 and D2 == 128
 

@@ -12,6 +12,7 @@ DGL has no ROCm build in this image, so PinGraph offers the same surface and add
 owns what the HIP kernels need: in-edge CSR and out-edge CSR per edge type (int32, device
 resident), cached per-level row lists, and the per-sweep scratch state.
 """
+import os
 import numpy as np
 import torch
 
@@ -367,6 +368,84 @@ class PinGraph:
         slots[cdeg > 4, 0] = -2
         max_in = [int(cdeg[np.asarray(nodes, dtype=np.int64)].max()) if len(nodes) else 0 for nodes in level_nodes]
         out = (torch.from_numpy(slots).to(self.device), torch.from_numpy(net_drv).to(self.device), max_in)
+        self._lists_store(key, level_nodes, out)
+        return out
+
+    BWD_PAIR_TILE_DRIVERS = 32     # drivers per tile (two 16-row MFMA blocks)
+    BWD_PAIR_TILE_SINKS = 32       # sinks a tile of whole drivers may hold (two per thread group); a driver with more is HEAVY:
+    BWD_PAIR_PART = 32             # ... cut into parts of this many sinks, one workgroup each
+
+    def level_bwd_pairs(self, level_nodes):
+        """Static tables of the paired reverse-sweep kernel (mmft_level_bwd_pair), or None when the schedule is not a folded
+        one: (cslots int32[N][4], pairs, scratch fp32[rows][128], counters int32[...]) on the device, with pairs[l // 2] for
+        every even level l = None (the pair keeps the per-level kernels) or dict(tiles=int32[ntiles][8], ntiles, sink_shift,
+        n_cell, n_net).  A pair qualifies when level l is a contiguous id range whose out-net edge list in CSR order IS the id
+        range of level l + 1 (DesignBatch numbers the nets of a level by driver).  Tile rows: (first driver id, count <= 32,
+        part, parts, first scratch row, counter index, first / end out-net CSR position of the tile's sinks) - parts = 0: whole drivers with at most BWD_PAIR_TILE_SINKS sinks
+        together; a driver with more sinks is cut into parts of BWD_PAIR_PART sinks, one tile each.  cslots[u] = the first four
+        cell consumers of u in out-edge order, -1 = none; with more than four, slot 3 = -2 - (out-cell CSR position of the
+        fourth).  scratch / counters are shared by the levels (their launches follow each other on one stream).  Cached per
+        list objects."""
+        fold = self.fold_schedule(level_nodes)
+        if fold is None:
+            return None
+        key = ('bwd_pairs',) + self._lists_key(level_nodes)
+        hit = self._lists_hit(key, level_nodes)
+        if hit is not None:
+            return hit[0]
+        N = self._n
+        optr, oidx = self._csr_host[('out', 'net')][0], self._csr_host[('out', 'net')][1]
+        cptr, cidx = self._csr_host[('out', 'cell')][0], self._csr_host[('out', 'cell')][1]
+        cdeg = np.diff(cptr)
+        cslots = np.full((N, 4), -1, dtype=np.int32)
+        for k in range(4):
+            rows = np.nonzero(cdeg > k)[0]
+            if rows.size == 0:
+                break
+            cslots[rows, k] = cidx[cptr[rows] + k]
+        many = np.nonzero(cdeg > 4)[0]
+        cslots[many, 3] = -2 - (cptr[many] + 3)
+        L = len(level_nodes)
+        pairs, max_rows, max_cnt = [], 1, 1
+        for l in range(0, L, 2):
+            rc = fold[l]['range']
+            n_net = fold[l + 1]['n'] if l + 1 < L else 0
+            rn = fold[l + 1]['range'] if n_net else (0, 0)
+            pair = None
+            if rc is not None and rn is not None:
+                row0, n = rc
+                e0, e1 = int(optr[row0]), int(optr[row0 + n])
+                fan = np.diff(optr[row0:row0 + n + 1])
+                ok = (e1 - e0 == n_net) and (n_net == 0 or bool((oidx[e0:e1] == np.arange(rn[0], rn[0] + n_net)).all()))
+                if ok:
+                    # greedy tiling: close a tile at 16 drivers, or when the next driver would push it past the sink target
+                    tiles, start, sinks, srow, cnt = [], 0, 0, 0, 0
+                    fl = fan.tolist()
+                    pos = optr[row0:row0 + n + 1].tolist()                # CSR position of every driver's first sink
+                    close = lambda a, b: tiles.append((row0 + a, b - a, 0, 0, 0, 0, pos[a], pos[b]))
+                    for i, f in enumerate(fl):
+                        heavy = f > self.BWD_PAIR_TILE_SINKS
+                        if i > start and (i - start == self.BWD_PAIR_TILE_DRIVERS or sinks + f > self.BWD_PAIR_TILE_SINKS or heavy):
+                            close(start, i)
+                            start, sinks = i, 0
+                        if heavy:
+                            parts = -(-f // self.BWD_PAIR_PART)
+                            tiles += [(row0 + i, 1, p, parts, srow, cnt, pos[i] + p * self.BWD_PAIR_PART,
+                                       min(pos[i + 1], pos[i] + (p + 1) * self.BWD_PAIR_PART)) for p in range(parts)]
+                            srow, cnt, start, sinks = srow + parts, cnt + 1, i + 1, 0
+                        else:
+                            sinks += f
+                    if n > start:
+                        close(start, n)
+                    # longest-running tiles first (heavy drivers' parts, then by sink count): the launch ends with short ones
+                    tiles.sort(key=lambda t: (0 if t[3] else 1, -(t[7] - t[6])))
+                    max_rows, max_cnt = max(max_rows, srow), max(max_cnt, cnt)
+                    t = torch.tensor(tiles, dtype=torch.int32).reshape(-1, 8).to(self.device)
+                    pair = dict(tiles=t, ntiles=len(tiles), sink_shift=(rn[0] - e0) if n_net else 0, n_cell=n, n_net=n_net)
+            pairs.append(pair)
+        out = (torch.from_numpy(cslots).to(self.device), pairs,
+               torch.zeros((max_rows, 128), dtype=torch.float32, device=self.device),
+               torch.zeros(max_cnt, dtype=torch.int32, device=self.device))
         self._lists_store(key, level_nodes, out)
         return out
 

@@ -462,6 +462,8 @@ EDGE_DRIVERS = True                 # folded gather: per-edge driver table (3-de
 FEAT_MLP_NO_HIDDEN = True           # bf16 mode: fc_cell_self / fc_net_self as one kernel each way, hidden activations recomputed
 FUSE_LEVEL_FWD = True               # bf16 mode: folded gather + fused MLP of a level pair in one launch (mmft_level_fwd_bf16)
 LEVEL_SLOTS = True                  # ... in its slot-table form where the level allows it (mmft_level_fwd_slots: fan-in <= 4, ranges)
+LEVEL_BWD_PAIRS = True              # reverse sweep: one launch per (cell level, net level above it) pair where the numbering
+                                    # allows it (PinGraph.level_bwd_pairs; mmft_level_bwd_pair)
 FOLD_LEVELS = True                  # folded forward chain (one gather per (net, cell) level PAIR) when the graph allows it
 FUSED_FIRST_LAYER_GRADS = True      # mmft_mlp2_first_layer_grads for the *_self MLPs (False: dgrad GEMM + wgrad GEMM)
 
@@ -599,7 +601,32 @@ class SweepFn(torch.autograd.Function):
         P = [_w(p) for p in st.params]
         w1g, w2g = P[8], P[10]
         out_net, out_cell, in_net_ptr = g.csr('out', 'net'), g.csr('out', 'cell'), g.out_net_weight()
+        pairs = None
+        if LEVEL_BWD_PAIRS and fast and st.fold is not None and st.wpack is not None and st.attn is None \
+                and getattr(st, 'level_lists', None) is not None:
+            pairs = g.level_bwd_pairs(st.level_lists)
+        paired = set()
+        if pairs is not None:
+            cslots, plist, pscratch, pcounters = pairs
+            if st.DHN is None:
+                st.DHN = st._buf('DHN', st.Hd)
         for level_id, rows in reversed(st.levels):
+            if level_id in paired:
+                continue
+            if pairs is not None:
+                # one launch for the pair (cell level l, net level l + 1): the net level comes first in this reverse order
+                cell_l = level_id - (level_id % 2)
+                pr = plist[cell_l // 2]
+                if pr is not None:
+                    paired.add(cell_l)
+                    mc = st.level_meta[cell_l] if st.level_meta else None
+                    mn = st.level_meta[cell_l + 1] if (st.level_meta and cell_l + 1 < len(st.level_meta)) else None
+                    nb = (mc['bytes_pull'] if mc else 0) + (mn['bytes_pull'] if mn else 0) + \
+                        (pr['n_cell'] * (8 * st.D + 8 * st.Hd) if cell_l > 0 else 0)
+                    ops.level_bwd_pair(st.G, st.h, st.A, st.LSE, st.DA, own, pr['tiles'], pr['ntiles'], out_net[0], pr['sink_shift'],
+                                       cslots, out_cell, pscratch, pcounters, st.wpack[2], st.wpack[3], st.HN, st.DHN, relu=st.relu, has_mlp=cell_l > 0,
+                                       alg_bytes=nb)
+                    continue
             if not rows.numel():
                 continue
             meta = st.level_meta[level_id] if st.level_meta else None

@@ -79,6 +79,24 @@ class DesignBatch:
             parts = [d.levels[l] + self.node_off[i] for i, d in enumerate(designs) if l < d.L]
             levels_old.append(np.concatenate(parts))
         if renumber:
+            # inside a net level the nodes are numbered by driver (the cell levels get their ids first): the sinks of one driver
+            # are then consecutive ids and the sink runs follow the drivers' order, which is what lets the reverse sweep handle a
+            # (cell level, net level) pair in one launch (PinGraph.level_bwd_pairs).  The order inside a level carries no
+            # meaning in the reference (graph.pull over a node set, src/model.py:186-204).
+            even = np.concatenate(levels_old[0::2]) if levels_old[0::2] else np.zeros(0, np.int64)
+            rank = np.full(self.N, -1, dtype=np.int64)
+            rank[even] = np.arange(even.shape[0])
+            nsrc = np.concatenate([d.net_src + self.node_off[i] for i, d in enumerate(designs)])
+            ndst = np.concatenate([d.net_dst + self.node_off[i] for i, d in enumerate(designs)])
+            indeg = np.bincount(ndst, minlength=self.N)
+            drv = np.full(self.N, -1, dtype=np.int64)
+            drv[ndst] = nsrc
+            eid = np.zeros(self.N, dtype=np.int64)                 # ... and inside a driver's run by edge order (= out-CSR order)
+            eid[ndst] = np.arange(ndst.shape[0])
+            for l in range(1, self.L, 2):
+                lv = levels_old[l]
+                if lv.size and bool((indeg[lv] == 1).all()) and bool((rank[drv[lv]] >= 0).all()):
+                    levels_old[l] = lv[np.lexsort((eid[lv], rank[drv[lv]]))]
             order = np.concatenate(levels_old[0::2] + levels_old[1::2])          # new id k <- old id order[k]
             rest = np.setdiff1d(np.arange(self.N), order)             # nodes in no level keep trailing ids
             order = np.concatenate([order, rest])

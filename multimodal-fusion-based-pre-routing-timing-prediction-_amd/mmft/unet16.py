@@ -15,6 +15,7 @@ and all weights re-packed to MFMA fragment order by one launch per step.  Select
 lib.get_math_mode() == 'bf16' and the input qualifies (`supported`); everything else takes the fp32 operators of cnn.py.
 """
 import ctypes
+import functools
 import math
 import weakref
 
@@ -235,6 +236,21 @@ def _bwd_sizes(N, H, W):
     return sizes, ws_bytes
 
 
+BATCH_REDUCE = True      # the 18 weight-gradient slab reductions of a backward pass as ONE launch (mmft_slab_reduce_batch)
+
+
+@functools.lru_cache(maxsize=16)
+def _slab_sizes(N, H, W):
+    """fp32 regions that keep every layer's weight-gradient slabs until the batched reduction at the end of the backward pass."""
+    lv, _ = _geometry(N, H, W)
+    q = lib.query
+    sizes = [('sw%d' % i, q('mmft_u16_conv3x3_wgrad_workspace_bytes', N, lv[_CONV[i][2]][0], lv[_CONV[i][2]][1], _CONV[i][0], _CONV[i][1]) // 4)
+             for i in range(1, 15)]
+    sizes += [('st%d' % k, q('mmft_u16_convt_wgrad_workspace_bytes', N, lv[u[4]][0], lv[u[4]][1], u[0]) // 4) for k, u in _UP.items()]
+    sizes += [('so', q('mmft_u16_outconv_bwd_workspace_bytes', N, H, W) // 4)]
+    return sizes
+
+
 def _run_forward(net, xn, pool_mode, packs, T, F, out, geom):
     """Every launch of UNet.forward (src/Unet.py:110-119) on the given buffers, in order; the weight pack comes first."""
     N, H, W = geom
@@ -290,19 +306,34 @@ def _make_sinks(net):
     return sinks
 
 
-def _run_backward(net, xn, pool_mode, packs, T, F, g, G, ws, geom, sinks):
-    """Every launch of the U-Net's backward pass on the given buffers, in order."""
+def _run_backward(net, xn, pool_mode, packs, T, F, g, G, ws, geom, sinks, SL=None):
+    """Every launch of the U-Net's backward pass on the given buffers, in order.  SL (named fp32 slab regions, _slab_sizes):
+    the weight-gradient kernels leave their slabs there and ONE launch at the end adds all of them up."""
     N, H, W = geom
     dev, st = lib.stream_args(g)
     lv, _ = _geometry(N, H, W)
     convs = _layers(net)
     ups = [net.up1.up, net.up2.up, net.up3.up]
     oc = net.outc.conv[0]
+    table = []                   # rows of mmft_slab_reduce_batch: slabs, out, splits, stride, elems, fold, accumulate
+
+    def reduce_later(slabs, out, splits, stride, elems, fold, accumulate):
+        table.append([slabs, out.data_ptr(), splits, stride, elems, fold, int(accumulate)])
+
     s_w, s_b = sinks[id(oc.weight)], sinks.get(id(oc.bias)) if oc.bias is not None else None
     if s_b is not None and s_b.accumulate != s_w.accumulate:
         raise RuntimeError('unet16: OutConv weight / bias sinks out of step')
-    lib.call('mmft_u16_outconv_bwd', T['a14'], oc.weight.detach(), oc.bias.detach() if oc.bias is not None else None, g, G['g14'],
-             s_w.out, s_b.out if s_b is not None else None, int(s_w.accumulate), N, H, W, pool_mode, ws, ws.numel() * 4, dev, st)
+    if SL is None:
+        lib.call('mmft_u16_outconv_bwd', T['a14'], oc.weight.detach(), oc.bias.detach() if oc.bias is not None else None, g, G['g14'],
+                 s_w.out, s_b.out if s_b is not None else None, int(s_w.accumulate), N, H, W, pool_mode, ws, ws.numel() * 4, dev, st)
+    else:
+        so = SL['so']
+        lib.call('mmft_u16_outconv_bwd', T['a14'], oc.weight.detach(), oc.bias.detach() if oc.bias is not None else None, g, G['g14'],
+                 None, None, 0, N, H, W, pool_mode, so, so.numel() * 4, dev, st)
+        ns = lib.query('mmft_u16_outconv_bwd_slabs', N, H, W)
+        reduce_later(so.data_ptr(), s_w.out, ns, 17, 16, 1, s_w.accumulate)
+        if s_b is not None:
+            reduce_later(so.data_ptr() + 64, s_b.out, ns, 17, 1, 1, s_b.accumulate)
 
     def conv_backward(i):
         Ci, Co, l, inp = _CONV[i]
@@ -315,8 +346,15 @@ def _run_backward(net, xn, pool_mode, packs, T, F, g, G, ws, geom, sinks):
                  N, h * w, Co, ws, ws.numel() * 4, dev, st)
         s_cw = sinks[id(cv.weight)]
         xin = xn if inp == 'x' else T[inp]
-        lib.call('mmft_u16_conv3x3_wgrad', xin, 1 if inp == 'x' else 0, G['dz%d' % i], s_cw.out, int(s_cw.accumulate), N, h, w, Ci, Co,
-                 ws, ws.numel() * 4, dev, st)
+        if SL is None:
+            lib.call('mmft_u16_conv3x3_wgrad', xin, 1 if inp == 'x' else 0, G['dz%d' % i], s_cw.out, int(s_cw.accumulate), N, h, w, Ci, Co,
+                     ws, ws.numel() * 4, dev, st)
+        else:
+            sw = SL['sw%d' % i]
+            lib.call('mmft_u16_conv3x3_wgrad', xin, 1 if inp == 'x' else 0, G['dz%d' % i], None, 0, N, h, w, Ci, Co,
+                     sw, sw.numel() * 4, dev, st)
+            reduce_later(sw.data_ptr(), s_cw.out, lib.query('mmft_u16_conv3x3_wgrad_slabs', N, h, w, Ci, Co), Co * 9 * Ci, Co * 9 * Ci, 1,
+                         s_cw.accumulate)
         if inp == 'x':
             return
         tgt = {'cat1': 'gcat1', 'cat2': 'gcat2', 'cat3': 'gcat3', 'p1': 'gp1', 'p2': 'gp2', 'p3': 'gp3'}.get(inp)
@@ -333,8 +371,16 @@ def _run_backward(net, xn, pool_mode, packs, T, F, g, G, ws, geom, sinks):
         s_uw, s_ub = sinks[id(up.weight)], sinks.get(id(up.bias)) if up.bias is not None else None
         if s_ub is not None and s_ub.accumulate != s_uw.accumulate:
             raise RuntimeError('unet16: ConvTranspose2d weight / bias sinks out of step')
-        lib.call('mmft_u16_convt_wgrad', T[uin], gslice, 2 * Co, s_uw.out, s_ub.out if s_ub is not None else None, int(s_uw.accumulate),
-                 N, uh, uw, uCi, ws, ws.numel() * 4, dev, st)
+        if SL is None:
+            lib.call('mmft_u16_convt_wgrad', T[uin], gslice, 2 * Co, s_uw.out, s_ub.out if s_ub is not None else None, int(s_uw.accumulate),
+                     N, uh, uw, uCi, ws, ws.numel() * 4, dev, st)
+        else:
+            stb = SL['st%d' % k]
+            lib.call('mmft_u16_convt_wgrad', T[uin], gslice, 2 * Co, None, None, 0, N, uh, uw, uCi, stb, stb.numel() * 4, dev, st)
+            ns, wel = lib.query('mmft_u16_convt_wgrad_slabs', N, uh, uw), 4 * Co * uCi
+            reduce_later(stb.data_ptr(), s_uw.out, ns, wel + 4 * Co, wel, 1, s_uw.accumulate)
+            if s_ub is not None:
+                reduce_later(stb.data_ptr() + 4 * wel, s_ub.out, ns, wel + 4 * Co, Co, 4, s_ub.accumulate)
         lib.call('mmft_u16_convt_dgrad', gslice, 2 * Co, packs.ptr('tb%d' % k), G[g_target], N, uh, uw, uCi, dev, st)
 
     def pool_backward(cat, C, l, gp, g_target):
@@ -348,6 +394,8 @@ def _run_backward(net, xn, pool_mode, packs, T, F, g, G, ws, geom, sinks):
     conv_backward(6); conv_backward(5); pool_backward('cat2', 32, 1, 'gp2', 'g4')
     conv_backward(4); conv_backward(3); pool_backward('cat3', 16, 0, 'gp1', 'g2')
     conv_backward(2); conv_backward(1)
+    if table:
+        lib.call('mmft_slab_reduce_batch', torch.tensor(table, dtype=torch.int64), len(table), dev, st)
 
 
 REPLAY = True           # eager callers (the per-level drop-in loop): second and later calls replay captured HIP graphs
@@ -450,11 +498,12 @@ class UNet16Fn(torch.autograd.Function):
                     gs, ws_bytes = _bwd_sizes(N, H, W)
                     rp.g = torch.empty_like(g)
                     rp.gbuf, rp.G = _arena(gs, torch.bfloat16, g.device)
+                    rp.sbuf, rp.SL = _arena(_slab_sizes(N, H, W), torch.float32, g.device, align=4) if BATCH_REDUCE else (None, None)
                     torch.cuda.synchronize()
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                         ws = lib.workspace(g.device, ws_bytes)
-                        _run_backward(net, xn, pool_mode, packs, T, F, rp.g, rp.G, ws, geom, sinks)
+                        _run_backward(net, xn, pool_mode, packs, T, F, rp.g, rp.G, ws, geom, sinks, rp.SL)
                     rp.bwd = graph
                 rp.g.copy_(g)
                 rp.bwd.replay()
@@ -465,7 +514,8 @@ class UNet16Fn(torch.autograd.Function):
         gs, ws_bytes = _bwd_sizes(N, H, W)
         _gbuf, G = _arena(gs, torch.bfloat16, g.device)
         ws = lib.workspace(g.device, ws_bytes)
-        _run_backward(net, xn, pool_mode, packs, T, F, g, G, ws, geom, sinks)
+        _sbuf, SL = _arena(_slab_sizes(N, H, W), torch.float32, g.device, align=4) if BATCH_REDUCE else (None, None)
+        _run_backward(net, xn, pool_mode, packs, T, F, g, G, ws, geom, sinks, SL)
         grads = {k: s.done() for k, s in sinks.items()}
         if rp is not None:
             rp.pending = None

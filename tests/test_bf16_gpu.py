@@ -287,6 +287,84 @@ def test_fused_level_kernel_equals_two_kernel_form(dev):
             assert torch.equal(other[5][k], res[2][5][k]), k
 
 
+@pytest.mark.parametrize('parts', [False, True])
+@pytest.mark.parametrize('fanout_skew', [False, True])
+def test_paired_reverse_level_kernel_equals_three_kernel_form(dev, fanout_skew, parts):
+    """bf16 mode: the reverse sweep with ONE launch per (cell level, net level above it) pair (mmft_level_bwd_pair: both pulls
+    and fc_cell_neigh's backward) against the three-launch form (mmft_level_bwd_pull twice, mmft_mlp2_rows_bf16 reversed).
+    parts=False: every driver whole inside one tile - the same additions in the same order as the pulls (run without their
+    workgroup-per-heavy-row path): bitwise equal G, DA, hidden gradients and parameter gradients.  parts=True (the shipped
+    setting): drivers with more than 48 sinks are cut into parts of 32 whose partial sums are added in part order by whichever
+    workgroup arrives last - another summation order for those rows (1e-5), and two runs must agree bit for bit.  With
+    fanout_skew some pins have more than four cell consumers (the CSR tail of the slot table)."""
+    from mmft import sweep as S
+    from mmft.pingraph import PinGraph
+    from mmft.synth import synth_design
+    from mmft.train import build_models, DesignBatch
+    kw = dict(fanin='irregular') if fanout_skew else {}
+    designs = [synth_design(N=9000, L=12, tile=32, seed=220 + i, end_frac=0.2, **kw) for i in range(2)]
+    b = DesignBatch(designs, dev)
+    sinks0 = PinGraph.BWD_PAIR_TILE_SINKS
+    heavy0 = ops.PAIR_HEAVY_OUT
+    try:
+        if not parts:
+            PinGraph.BWD_PAIR_TILE_SINKS = 1 << 30
+        pairs = b.graph.level_bwd_pairs(b.level_nodes)
+        assert pairs is not None and all(p is not None for p in pairs[1])
+        fan = np.diff(b.graph.csr_host('out', 'net')[0])
+        assert fan.max() > 64
+        nheavy = sum(int((p['tiles'][:, 3] > 0).sum()) for p in pairs[1])
+        assert (nheavy > 0) == parts
+        if fanout_skew:
+            assert int((pairs[0][:, 3] <= -2).sum()) > 0
+        pmodel, _ = build_models(map_size=designs[0].map_size, device=dev, seed=9)
+        ends = b.select([np.arange(0, d.num_paths, 3) for d in designs])[0]
+        all_rows = torch.as_tensor(np.concatenate([np.asarray(x) for x in b.level_nodes]), device=dev).long()
+        rows2 = torch.as_tensor(np.concatenate([np.asarray(x) for x in b.level_nodes[2::2]]), device=dev).long()
+        res, names = [], []
+        for paired in (True, True, False):
+            S.LEVEL_BWD_PAIRS = paired
+            ops.PAIR_HEAVY_OUT = 1 << 30
+            g = b.graph
+            g.__dict__.get('_level_cache', {}).clear()
+            g.ndata['h'] = torch.zeros((b.N, 128), dtype=torch.float32, device=dev)
+            for p in pmodel.gnn.parameters():
+                p.grad = None
+            out = S.sweep_forward_all(pmodel.gnn, g, b.level_nodes, ends)
+            st = g._sweep
+            assert st.wpack is not None and st.fold is not None
+            lib.prof_reset()
+            lib.prof_enable(True)
+            (out * out).sum().backward()
+            torch.cuda.synchronize()
+            lib.prof_enable(False)
+            names.append({r['name'] for r in lib.prof_report()})
+            res.append((st.G[all_rows].clone(), st.DA[rows2].clone(), st.DHN[rows2].clone(),
+                        {k: p.grad.clone() for k, p in pmodel.gnn.named_parameters() if p.grad is not None}))
+    finally:
+        S.LEVEL_BWD_PAIRS = True
+        ops.PAIR_HEAVY_OUT = heavy0
+        PinGraph.BWD_PAIR_TILE_SINKS = sinks0
+    assert 'level_bwd_pair_kernel' in names[0] and 'level_bwd_pull_kernel' not in names[0]
+    assert 'level_bwd_pull_kernel' in names[2] and 'level_bwd_pair_kernel' not in names[2]
+    assert int(pairs[3].abs().sum()) == 0                                    # the part counters are back at zero
+    assert float(res[0][0].abs().max()) > 0 and float(res[0][1].abs().max()) > 0
+    for i in range(3):                                                       # two paired runs: bit for bit
+        assert torch.equal(res[0][i], res[1][i])
+    for k in res[0][3]:
+        assert torch.equal(res[0][3][k], res[1][3][k]), k
+    if not parts:
+        for i in range(3):
+            assert torch.equal(res[0][i], res[2][i])
+        for k in res[2][3]:
+            assert torch.equal(res[0][3][k], res[2][3][k]), k
+    else:
+        for i in range(3):
+            assert rel_err(res[0][i], res[2][i]) < 1e-5
+        for k in res[2][3]:
+            assert rel_err(res[0][3][k], res[2][3][k]) < 1e-4, k
+
+
 @pytest.mark.parametrize('fin,n,row0', [(36, 1000, 7), (2, 4099, 0), (36, 70000, 128), (5, 33, 3)])
 @pytest.mark.parametrize('representable', [True, False])
 def test_feature_mlp_without_hidden_tensor(dev, fin, n, row0, representable):

@@ -338,3 +338,68 @@ def test_unet_module_bf16_storage_vs_fp64_oracle(dev, N, H, W, pooling):
             assert rel_err(v, pc[k]) < 1e-2, k
         if 'num_batches' in k:
             assert int(v) == N
+
+
+def test_slab_reduce_batch(dev):
+    """mmft_slab_reduce_batch: several slab reductions (vector and scalar forms, strided slabs that carry two results, a folded
+    bias, accumulate on / off) in one launch; integer-valued floats, so every summation order gives the same bits."""
+    gen = torch.Generator().manual_seed(5)
+    cases = [dict(splits=512, elems=2304, stride=2304, fold=1, off=0, acc=0),
+             dict(splits=37, elems=4 * 64 * 128, stride=4 * 64 * 128 + 4 * 64, fold=1, off=0, acc=1),
+             dict(splits=37, elems=64, stride=4 * 64 * 128 + 4 * 64, fold=4, off=4 * 64 * 128, acc=0),
+             dict(splits=1024, elems=16, stride=17, fold=1, off=0, acc=1),
+             dict(splits=1024, elems=1, stride=17, fold=1, off=16, acc=0),
+             dict(splits=3, elems=10, stride=12, fold=1, off=0, acc=0)]
+    bufs, rows, want, outs = {}, [], [], []
+    for c in cases:
+        key = (c['splits'], c['stride'])
+        if key not in bufs:
+            bufs[key] = torch.randint(-8, 9, (c['splits'], c['stride']), generator=gen).float().to(dev)
+        sl = bufs[key]
+        out = torch.randint(-8, 9, (c['elems'],), generator=gen).float().to(dev)
+        ref = sl[:, c['off']:c['off'] + c['fold'] * c['elems']].reshape(c['splits'], c['fold'], c['elems']).sum((0, 1))
+        want.append(ref + out if c['acc'] else ref)
+        outs.append(out)
+        rows.append([sl.data_ptr() + 4 * c['off'], out.data_ptr(), c['splits'], c['stride'], c['elems'], c['fold'], c['acc']])
+    d, st = lib.stream_args(outs[0])
+    lib.call('mmft_slab_reduce_batch', torch.tensor(rows, dtype=torch.int64), len(rows), d, st)
+    torch.cuda.synchronize()
+    for o, w in zip(outs, want):
+        assert torch.equal(o, w)
+    with pytest.raises(RuntimeError):
+        lib.call('mmft_slab_reduce_batch', torch.tensor(rows * 5, dtype=torch.int64), len(rows) * 5, d, st)
+
+
+def test_batched_reduce_equals_per_layer_reduce(dev):
+    """UNet backward with the weight-gradient slabs reduced by one launch at the end against the per-layer reductions: the same
+    slabs; the convolution layers add them in the same order (bitwise), the transposed convolutions and OutConv in another."""
+    import Unet
+    torch.manual_seed(3)
+    net = Unet.UNet('max').to(dev)
+    net.set_per_sample_stats(True)
+    net.train()
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(5)).to(dev)
+    res = []
+    for batch in (True, False):
+        unet16.BATCH_REDUCE = batch
+        try:
+            for p in net.parameters():
+                p.grad = None
+            with lib.math_mode('bf16'):
+                lib.prof_reset()
+                lib.prof_enable(True)
+                out = net(x)
+                (out * out).sum().backward()
+                torch.cuda.synchronize()
+                lib.prof_enable(False)
+                names = {r['name'].split('<')[0] for r in lib.prof_report()}
+            assert ('slab_reduce_batch_kernel' in names) == batch and ('slab_reduce_kernel' in names) != batch, names
+            res.append({k: p.grad.clone() for k, p in net.named_parameters()})
+        finally:
+            unet16.BATCH_REDUCE = True
+    for k in res[0]:
+        a, b = res[0][k], res[1][k]
+        if a.dim() == 4 and a.shape[-1] == 3:
+            assert torch.equal(a, b), k
+        else:
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7, k

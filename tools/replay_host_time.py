@@ -7,6 +7,10 @@ from mmft import lib
 from mmft.synth import synth_design
 from mmft.train import build_models, TrainStep, GraphedTrainStep
 lib.set_math_mode(os.environ.get('MMFT_MATH', 'bf16'))
+from mmft import sweep as _S, unet16 as _U
+_S.LEVEL_BWD_PAIRS = os.environ.get('PAIRS', '1') == '1'
+_U.BATCH_REDUCE = os.environ.get('BATCHRED', '1') == '1'
+print('pairs', _S.LEVEL_BWD_PAIRS, 'batch reduce', _U.BATCH_REDUCE)
 dev = torch.device('cuda:0')
 designs = [synth_design(N=65536, L=64, tile=256, seed=9294 + i) for i in range(8)]
 pm, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=9294)
@@ -73,3 +77,30 @@ if gs.pieces:
     a, b_ = t(onA), t(onB)
     print(f'forward pieces in isolation: A (sweep, side) {a:.3f} ms, B (U-Net, main) {b_:.3f} ms, sum {a + b_:.3f}; '
           f'both (A issued first) {t(both):.3f} ms, both (B issued first) {t(both_rev):.3f} ms')
+
+    def piece(name, stream=None):
+        g = getattr(gs, name)
+
+        def run():
+            if stream is None:
+                g.replay()
+            else:
+                stream.wait_stream(main)
+                with torch.cuda.stream(stream):
+                    g.replay()
+                main.wait_stream(stream)
+        return t(run)
+
+    def bwd_both():
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            gs.gbA.replay()
+        gs.gbB.replay()
+        main.wait_stream(side)
+    # the pieces replay on whatever the previous replay left in the buffers: timing only
+    res = {n: piece(n, side if n in ('gA', 'gbA') else None) for n in ('gA', 'gB', 'gH', 'gbA', 'gbB')}
+    res['adam'] = t(lambda: ts.optim.step())
+    res['bA+bB'] = t(bwd_both)
+    print('pieces in isolation (ms):', {k: round(v, 3) for k, v in res.items()})
+    print('ideal overlap: %.3f ms; serial: %.3f ms' % (max(res['gA'], res['gB']) + res['gH'] + max(res['gbA'], res['gbB']) + res['adam'],
+                                                      sum(res[k] for k in ('gA', 'gB', 'gH', 'gbA', 'gbB', 'adam'))))
