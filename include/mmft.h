@@ -52,6 +52,9 @@ int mmft_prof_report(char* buf, int cap);
 /* Algorithmic flops / bytes of the calling thread's NEXT instrumented launch that records none itself (the masked
  * projection and whole-workgroup segment sums: their work depends on per-step run / edge counts only the host has). */
 int mmft_prof_hint(double flops, double bytes);
+/* One device timestamp (wall_clock64: 100 MHz) written to slots[index] by a one-thread launch on `stream`: marks a point of a
+ * stream inside a captured graph, where host timers and the kernel trace (which serialises dispatches) see nothing. */
+int mmft_prof_stamp(unsigned long long* slots, int index, int device, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense layers  --  replaces th.nn.Linear / LeakyReLU inside MLP (src/model.py:10-24), used by

@@ -63,7 +63,20 @@ __device__ __forceinline__ float cell_consumer_term(float g, float da, float hv,
   return __fadd_rn(g, __fmul_rn(w, __fsub_rn(__fadd_rn(1.0f, hv), a)));
 }
 
-struct SoftAcc {
+// exp / log of the online softmax.  FAST (bf16 math mode): the hardware's v_exp_f32 / v_log_f32 (base 2, one multiply for the
+// base change, each rounded on its own so that every kernel that shares these helpers produces the same bits): the gather of a
+// level is 32 exponentials per lane and row, ~20 VALU instructions each in the accurate form - a third of the kernel's time.
+template <bool FAST>
+__device__ __forceinline__ float fg_exp(float x) {
+  return FAST ? __builtin_amdgcn_exp2f(__fmul_rn(x, 1.44269504088896340736f)) : expf(x);
+}
+template <bool FAST>
+__device__ __forceinline__ float fg_log(float x) {
+  return FAST ? __fmul_rn(__builtin_amdgcn_logf(x), 0.69314718055994530942f) : logf(x);
+}
+
+template <bool FAST>
+struct SoftAccT {
   fg_f32x4 mx, s, acc;
   __device__ __forceinline__ void init() {
     mx = fg_f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -74,17 +87,19 @@ struct SoftAcc {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float m_new = fmaxf(mx[j], x[j]);
-      float scale = expf(mx[j] - m_new);
-      float p = expf(x[j] - m_new);
+      float scale = fg_exp<FAST>(mx[j] - m_new);      // exp(-inf) = 0 on the first edge
+      float p = fg_exp<FAST>(x[j] - m_new);
       s[j] = s[j] * scale + p;
       acc[j] = acc[j] * scale + p * x[j];
       mx[j] = m_new;
     }
   }
 };
+typedef SoftAccT<false> SoftAcc;
 
 // Adds the edges e0, e0 + stride, ... < e1 of one cell row to `sa`, in that order.
-__device__ __forceinline__ void fold_gather_edges(const FoldSrc& s, int e0, int e1, int stride, int c, SoftAcc& sa) {
+template <bool FAST>
+__device__ __forceinline__ void fold_gather_edges(const FoldSrc& s, int e0, int e1, int stride, int c, SoftAccT<FAST>& sa) {
   if (!s.ic_drv) {
     for (int e = e0; e < e1; e += stride) {
       const int u = s.ic_idx[e];
@@ -118,7 +133,7 @@ __device__ __forceinline__ void fold_gather_edges(const FoldSrc& s, int e0, int 
     for (int k = 0; k < 4; ++k) {
       fg_f32x4 x = folded[k] ? fg_finish_net(a[k], p[k], s.relu) : a[k];   // mean over ONE in-edge = the driver's row itself
       if (folded[k] && d[k] < 0) x = fold_net_value(s, u[k], c);           // net with no or several drivers (not in a folded schedule)
-      SoftAcc nx = sa;
+      SoftAccT<FAST> nx = sa;
       nx.add(x);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

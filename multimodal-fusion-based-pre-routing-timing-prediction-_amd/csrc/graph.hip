@@ -222,6 +222,7 @@ __global__ void __launch_bounds__(256) level_bwd_pull_kernel(
 // thread groups stride over the edges with an online softmax each and their (max, sum, weighted sum) triples are merged
 // in a fixed order.
 // ------------------------------------------------------------------------------------------------------------------
+template <bool FAST>
 __global__ void __launch_bounds__(256) pair_fwd_gather_kernel(
     float* __restrict__ h, const float* __restrict__ PRE, long long ld, int D, const int* __restrict__ in_ptr,
     const int* __restrict__ in_idx, const int* __restrict__ ic_ptr, const int* __restrict__ ic_idx, int net_row0, int n_net,
@@ -239,7 +240,7 @@ __global__ void __launch_bounds__(256) pair_fwd_gather_kernel(
       if (active && !active[v]) continue;                    // block-uniform: outside this step's fan-in cone
       const int e0 = ic_ptr[v], e1 = ic_ptr[v + 1];
       if (tg < act) {
-        SoftAcc sa;
+        SoftAccT<FAST> sa;
         sa.init();
         fold_gather_edges(fs, e0 + tg, e1, act, c, sa);
         pm[tg][c >> 2] = sa.mx; ps[tg][c >> 2] = sa.s; pa[tg][c >> 2] = sa.acc;
@@ -254,7 +255,7 @@ __global__ void __launch_bounds__(256) pair_fwd_gather_kernel(
         for (int t = 0; t < act; ++t)                        // fixed order; empty partials carry max = -inf, sum = 0
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            float sc = ps[t][c >> 2][j] > 0.f ? expf(pm[t][c >> 2][j] - M[j]) : 0.f;
+            float sc = ps[t][c >> 2][j] > 0.f ? fg_exp<FAST>(pm[t][c >> 2][j] - M[j]) : 0.f;
             S[j] += ps[t][c >> 2][j] * sc;
             AC[j] += pa[t][c >> 2][j] * sc;
           }
@@ -262,7 +263,7 @@ __global__ void __launch_bounds__(256) pair_fwd_gather_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           a[j] = AC[j] / S[j];
-          l[j] = M[j] + logf(S[j]);
+          l[j] = M[j] + fg_log<FAST>(S[j]);
         }
         st4(A + (long long)v * lda + c, a);
         if (LSE) st4(LSE + (long long)v * lda + c, l);
@@ -285,7 +286,7 @@ __global__ void __launch_bounds__(256) pair_fwd_gather_kernel(
     const int e0 = ic_ptr[v], e1 = ic_ptr[v + 1];
     if (e1 - e0 > heavy_thresh && heavy) continue;
     if (active && !active[v]) continue;
-    SoftAcc sa;
+    SoftAccT<FAST> sa;
     sa.init();
     fold_gather_edges(fs, e0, e1, 1, c, sa);
     f32x4 a = {0.f, 0.f, 0.f, 0.f}, l = {0.f, 0.f, 0.f, 0.f};
@@ -293,7 +294,7 @@ __global__ void __launch_bounds__(256) pair_fwd_gather_kernel(
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         a[j] = sa.acc[j] / sa.s[j];
-        l[j] = sa.mx[j] + logf(sa.s[j]);
+        l[j] = sa.mx[j] + fg_log<FAST>(sa.s[j]);
       }
     }
     st4(A + (long long)v * lda + c, a);
@@ -723,10 +724,15 @@ int mmft_pair_fwd_gather(float* h, const float* pre, long long ld, int D, const 
   DeviceGuard dg(device);
   const int light = node_grid(n, D);
   const int hb = nheavy < 512 ? nheavy : 512;
-  MMFT_LAUNCH("pair_fwd_gather_kernel", 0.0, alg_bytes > 0 ? (double)alg_bytes : 3.0 * 4.0 * n * D, pair_fwd_gather_kernel,
-              dim3(light + hb), dim3(256), (hipStream_t)stream, h, pre, ld, D, in_net_indptr, in_net_indices, in_cell_indptr,
-              in_cell_indices, net_row0, n_net, cell_rows, cell_row0, n_cell, A, LSE, lda, relu,
-              nheavy ? heavy_rows : nullptr, nheavy, light, heavy_thresh, active, in_cell_driver);
+  const double gby = alg_bytes > 0 ? (double)alg_bytes : 3.0 * 4.0 * n * D;
+  if (math_mode() == MMFT_MATH_BF16)             // the hardware exp / log of the bf16 mode's level kernels (fold_gather.h)
+    MMFT_LAUNCH("pair_fwd_gather_kernel", 0.0, gby, pair_fwd_gather_kernel<true>, dim3(light + hb), dim3(256), (hipStream_t)stream, h,
+                pre, ld, D, in_net_indptr, in_net_indices, in_cell_indptr, in_cell_indices, net_row0, n_net, cell_rows, cell_row0,
+                n_cell, A, LSE, lda, relu, nheavy ? heavy_rows : nullptr, nheavy, light, heavy_thresh, active, in_cell_driver);
+  else
+    MMFT_LAUNCH("pair_fwd_gather_kernel", 0.0, gby, pair_fwd_gather_kernel<false>, dim3(light + hb), dim3(256), (hipStream_t)stream, h,
+                pre, ld, D, in_net_indptr, in_net_indices, in_cell_indptr, in_cell_indices, net_row0, n_net, cell_rows, cell_row0,
+                n_cell, A, LSE, lda, relu, nheavy ? heavy_rows : nullptr, nheavy, light, heavy_thresh, active, in_cell_driver);
   return check_launch("pair_fwd_gather");
 }
 

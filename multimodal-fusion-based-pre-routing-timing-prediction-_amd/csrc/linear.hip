@@ -307,6 +307,10 @@ __global__ void __launch_bounds__(256) act_fwd_kernel(const float* __restrict__ 
   }
 }
 
+// one device timestamp (100 MHz wall clock) into slots[index]: marks a point of a stream inside a captured graph, where host
+// timers and the profiler's serialising kernel trace see nothing (tools/step_timeline.py)
+__global__ void stamp_kernel(unsigned long long* slots, int index) { slots[index] = wall_clock64(); }
+
 }  // namespace mmft
 
 using namespace mmft;
@@ -327,6 +331,13 @@ int mmft_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(mmft::g_prof_mu);
   mmft::g_prof = on != 0;
   return MMFT_OK;
+}
+
+int mmft_prof_stamp(unsigned long long* slots, int index, int device, void* stream) {
+  MMFT_REQUIRE(slots && index >= 0, "prof_stamp: bad arguments");
+  DeviceGuard dg(device);
+  hipLaunchKernelGGL(mmft::stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slots, index);
+  return check_launch("prof_stamp");
 }
 
 int mmft_prof_hint(double flops, double bytes) {

@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(512) level_fwd_bf16_kernel(LevelFwdArgs a) {
     if (live_row(r)) {
       const int v = row_of(r);
       const int e0 = a.ic_ptr[v], e1 = a.ic_ptr[v + 1];
-      SoftAcc sa;
+      SoftAccT<true> sa;
       sa.init();
       fold_gather_edges(fs, e0, e1, 1, c, sa);
       f32x4 lv = {0.f, 0.f, 0.f, 0.f};
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(512) level_fwd_bf16_kernel(LevelFwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           av[j] = sa.acc[j] / sa.s[j];
-          lv[j] = sa.mx[j] + logf(sa.s[j]);
+          lv[j] = sa.mx[j] + fg_log<true>(sa.s[j]);
         }
       }
       *reinterpret_cast<f32x4*>(a.A + (long long)v * a.ld + c) = av;
@@ -393,12 +393,12 @@ __global__ void __launch_bounds__(512) level_fwd_slots_kernel(LevelSlotsArgs a) 
         xa[k] = *reinterpret_cast<const f32x4*>(a.h + (long long)(hrow[k] >= 0 ? hrow[k] : h0) * a.ld + gc);
         xp[k] = *reinterpret_cast<const f32x4*>(a.pre + (long long)(prow[k] >= 0 ? prow[k] : a.net_row0) * a.ld + gc);
       }
-      SoftAcc sa;
+      SoftAccT<true> sa;
       sa.init();
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const f32x4 x = prow[k] >= 0 ? fg_finish_net(xa[k], xp[k], a.relu) : xa[k];
-        SoftAcc nx = sa;
+        SoftAccT<true> nx = sa;
         nx.add(x);
         const bool ok = hrow[k] >= 0;
 #pragma unroll
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(512) level_fwd_slots_kernel(LevelSlotsArgs a) 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           av[j] = sa.acc[j] / sa.s[j];
-          lv[j] = sa.mx[j] + logf(sa.s[j]);
+          lv[j] = sa.mx[j] + fg_log<true>(sa.s[j]);
         }
       }
       *reinterpret_cast<f32x4*>(a.A + (long long)v * a.ld + gc) = av;

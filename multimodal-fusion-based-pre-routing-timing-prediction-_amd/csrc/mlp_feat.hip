@@ -15,6 +15,7 @@
 // Lane layouts are those of mlp2_bf16.hip: A = weights / transposed tiles (lane = output feature, 8 consecutive k),
 // B = row tiles (lane = row or feature, 8 consecutive k), D[m][n] at lane (n = lane & 15, q = lane >> 4) = rows 4q..4q+3.
 #include "gemm_bf16.h"
+#include "tr_read.h"
 
 namespace mmft {
 
@@ -153,17 +154,18 @@ struct FeatBwdArgs {
 
 template <int KS>
 __global__ void __launch_bounds__(512) mlp2_feat_bwd_kernel(FeatBwdArgs a) {
-  constexpr int BM = 32, KP = KS * 32, XS = KP + 8, GS = MF_D2 + 8, TS = BM + 8, KB = KP / 16;
-  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];       // 70 KB: above the static limit
-  unsigned short* xs = lds;                       // X tile, natural    [row][k]
-  unsigned short* gs = xs + BM * XS;              // G tile, natural    [row][d2]
-  unsigned short* xT = gs + BM * GS;              // X tile, transposed [k][row]
-  unsigned short* gT = xT + KP * TS;              // G tile, transposed [d2][row]
-  unsigned short* hT = gT + MF_D2 * TS;           // H tile, transposed [col][row]
-  unsigned short* dT = hT + MF_HD * TS;           // dH tile, transposed [col][row]
-  f32x4(*gred)[32] = reinterpret_cast<f32x4(*)[32]>(hT);      // end of the kernel only (16 x 32 x 16 B <= hT)
+  // every tile lives in LDS in its natural [row][column] layout; the contractions over the tile's rows read their operands
+  // with the hardware-transposed read (tr_read.h) - pitches of 16 x odd elements
+  constexpr int BM = 32, KP = KS * 32, XS = KP + 16, GS = MF_D2 + 16, HS = MF_HD + 16, KB = KP / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  unsigned short* xs = lds;                       // X tile  [row][k]
+  unsigned short* gs = xs + BM * XS;              // G tile  [row][d2]
+  unsigned short* hs = gs + BM * GS;              // H tile  [row][col]
+  unsigned short* ds = hs + BM * HS;              // dH tile [row][col]
+  f32x4(*gred)[32] = reinterpret_cast<f32x4(*)[32]>(hs);      // end of the kernel only (16 x 32 x 16 B <= hs)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, q = lane >> 4;
+  const int trr = tr_lane_row(lane), trc = tr_lane_col(lane);
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
   // weights in registers for the life of the workgroup
@@ -213,7 +215,7 @@ __global__ void __launch_bounds__(512) mlp2_feat_bwd_kernel(FeatBwdArgs a) {
   };
   if ((int)blockIdx.x < ntiles) request(blockIdx.x);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    // ---- deposit G (natural + transposed) and X (natural + transposed); rows past the end are zero
+    // ---- deposit G and X; rows past the end are zero
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int e = tid + it * 512, r = e >> 5, c = (e & 31) * 4;          // (row, 4 consecutive d2): c is the same for both
@@ -221,17 +223,11 @@ __global__ void __launch_bounds__(512) mlp2_feat_bwd_kernel(FeatBwdArgs a) {
       gsum += v;
       const unsigned lo = pack_bf16(v.x, v.y), hi = pack_bf16(v.z, v.w);
       *reinterpret_cast<unsigned long long*>(gs + r * GS + c) = ((unsigned long long)hi << 32) | lo;
-      gT[(c + 0) * TS + r] = (unsigned short)(lo & 0xffff);
-      gT[(c + 1) * TS + r] = (unsigned short)(lo >> 16);
-      gT[(c + 2) * TS + r] = (unsigned short)(hi & 0xffff);
-      gT[(c + 3) * TS + r] = (unsigned short)(hi >> 16);
     }
 #pragma unroll
     for (int k = 0; k < NXE; ++k) {
       const int e = tid + k * 512, r = e / KP, kk = e % KP;
-      const unsigned short b = mf_bf16(xr[k]);
-      xs[r * XS + kk] = b;
-      xT[kk * TS + r] = b;
+      xs[r * XS + kk] = mf_bf16(xr[k]);
     }
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) request(tile + gridDim.x);
@@ -265,27 +261,25 @@ __global__ void __launch_bounds__(512) mlp2_feat_bwd_kernel(FeatBwdArgs a) {
         dsum[j] += dh;
         const unsigned hl = pack_bf16(hv.x, hv.y), hh = pack_bf16(hv.z, hv.w);
         const unsigned dl = pack_bf16(dh.x, dh.y), dhh = pack_bf16(dh.z, dh.w);
-        hT[(nn + 0) * TS + m] = (unsigned short)(hl & 0xffff); hT[(nn + 1) * TS + m] = (unsigned short)(hl >> 16);
-        hT[(nn + 2) * TS + m] = (unsigned short)(hh & 0xffff); hT[(nn + 3) * TS + m] = (unsigned short)(hh >> 16);
-        dT[(nn + 0) * TS + m] = (unsigned short)(dl & 0xffff); dT[(nn + 1) * TS + m] = (unsigned short)(dl >> 16);
-        dT[(nn + 2) * TS + m] = (unsigned short)(dhh & 0xffff); dT[(nn + 3) * TS + m] = (unsigned short)(dhh >> 16);
+        *reinterpret_cast<unsigned long long*>(hs + m * HS + nn) = ((unsigned long long)hh << 32) | hl;
+        *reinterpret_cast<unsigned long long*>(ds + m * HS + nn) = ((unsigned long long)dhh << 32) | dl;
       }
     }
     __syncthreads();
-    // ---- contractions over the tile's 32 rows (one K step): dW2^T[col][d2] += H^T G, dW1^T... [col][k] += dH^T X
+    // ---- contractions over the tile's 32 rows (one K step): dW2^T[col][d2] += H^T G, dW1^T[col][k] += dH^T X
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int col = wave * 32 + j * 16 + r16;
-      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hT + col * TS + q * 8);
-      const bf16x8 df = *reinterpret_cast<const bf16x8*>(dT + col * TS + q * 8);
+      const int col0 = wave * 32 + j * 16;
+      const bf16x8 hf = __builtin_bit_cast(bf16x8, tr_read_pair(hs + trr * HS + col0 + trc, 16 * HS));
+      const bf16x8 df = __builtin_bit_cast(bf16x8, tr_read_pair(ds + trr * HS + col0 + trc, 16 * HS));
 #pragma unroll
       for (int d = 0; d < 8; ++d) {
-        const bf16x8 gf = *reinterpret_cast<const bf16x8*>(gT + (d * 16 + r16) * TS + q * 8);
+        const bf16x8 gf = __builtin_bit_cast(bf16x8, tr_read_pair(gs + trr * GS + d * 16 + trc, 16 * GS));
         dw2[j][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf, gf, dw2[j][d], 0, 0, 0);
       }
 #pragma unroll
       for (int k = 0; k < KB; ++k) {
-        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xT + (k * 16 + r16) * TS + q * 8);
+        const bf16x8 xf = __builtin_bit_cast(bf16x8, tr_read_pair(xs + trr * XS + k * 16 + trc, 16 * XS));
         dw1[j][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, xf, dw1[j][k], 0, 0, 0);
       }
     }
@@ -333,8 +327,8 @@ __global__ void __launch_bounds__(512) mlp2_feat_bwd_kernel(FeatBwdArgs a) {
 
 template <int KS>
 constexpr int feat_bwd_lds() {
-  constexpr int BM = 32, KP = KS * 32, XS = KP + 8, GS = MF_D2 + 8, TS = BM + 8;
-  return (BM * XS + BM * GS + KP * TS + MF_D2 * TS + 2 * MF_HD * TS) * 2;
+  constexpr int BM = 32, KP = KS * 32, XS = KP + 16, GS = MF_D2 + 16, HS = MF_HD + 16;
+  return (BM * XS + BM * GS + 2 * BM * HS) * 2;
 }
 
 static inline long long feat_slab(int fin) { return (long long)MF_HD * fin + MF_HD + (long long)MF_D2 * MF_HD + MF_D2; }
