@@ -115,13 +115,14 @@ def prof_report():
 
 SEC8D_FWD = ('level_fwd_bf16_kernel', 'level_fwd_slots_kernel', 'pair_fwd_gather_kernel', 'seg_mean_fwd_kernel',
              'seg_softmax_sum_fwd_kernel', 'seg_attn_fwd_kernel')
-SEC8D_BWD = ('level_bwd_pull_kernel', 'level_bwd_pull_attn_kernel')
+SEC8D_BWD = ('level_bwd_pull_kernel', 'level_bwd_pull_attn_kernel', 'level_bwd_pair_kernel')
 
 
 def sec8d_aggregation(designs, rows, nprof, D=128, s=4):
     """aggregation bytes per design-step, forward `s D (E + N_d) + 4 E + 4 (N_d + L)`, backward
     `s D (3 E + 2 N_d) + 4 E` (E = net + cell edges, N_d = nodes of level >= 1, s = bytes per stored element), summed
-    over this rank's designs and divided by the device time of ALL launches of the kernels that carry that traffic."""
+    over this rank's designs and divided by the device time of ALL launches of the kernels that carry that traffic (the fused
+    level kernels of the bf16 mode run the level MLP inside the same launches: their whole duration counts)."""
     fwd = bwd = 0.0
     for d in designs:
         E = int(d.net_src.shape[0]) + int(d.cell_src.shape[0])
@@ -250,7 +251,7 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--dtype', default='bf16', choices=['f32', 'bf16'],
                     help='bf16 (default: BASELINE.json configs[1] is quoted as "1xMI355X bf16"): bf16 operands / fp32 '
-                         'accumulate on the MFMA-bound contractions, tensors in HBM fp32; the same schedule is then replayed '
+                         'accumulate on the MFMA-bound contractions, U-Net activations stored bf16; the same schedule is then replayed '
                          'in exact fp32 for the held-out MAE drift and the fp32 step time.  f32: exact fp32 MFMA everywhere '
                          '(the 1e-4 parity mode the GPU tests run in)')
     ap.add_argument('--cpu-steps', type=int, default=10)
@@ -313,6 +314,11 @@ def main():
             log(f'HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly')
             stepper = ts
 
+    if args.mode == 'dropin':
+        import gc
+        gc.collect()
+        gc.freeze()     # the eager per-level loop allocates python objects per call: keep the designs' ~4 M list entries out of
+                        # the collector's generations (a full collection in the middle of a step is a 50 ms stall)
     for _w in range(args.warmup):
         stepper.step(sample_paths(designs, args.batch_paths, rng))
         torch.cuda.synchronize()
@@ -487,12 +493,12 @@ def main():
             'config': {
                 'workload': f'{"config B" if (args.designs, args.nodes, args.levels, args.tile) == (8, 65536, 64, 256) else "custom"}: {args.designs} designs/step/GPU, {args.nodes}-node netlist, {args.levels} levels, '
                             f'{args.tile}x{args.tile} tile, {args.batch_paths} endpoints/design, UNet(max), '
-                            + ('fp32' if args.dtype == 'f32' else 'bf16 operands / fp32 accumulate on the MFMA-bound contractions (tensors in HBM fp32)'),
+                            + ('fp32' if args.dtype == 'f32' else 'bf16 operands / fp32 accumulate on the MFMA-bound contractions; U-Net activations and their gradients stored bf16, netlist tensors, statistics, parameters and gradients fp32'),
                 'designs_per_step_per_gpu': args.designs, 'nodes': args.nodes, 'levels': args.levels,
                 'tile': args.tile, 'endpoints_per_design': args.batch_paths, 'cone_pruning': bool(args.cone),
                 'parallelism': f'dp{world} (designs sharded, one all-reduce of the flat gradient per step)',
                 'launch': (('five single-stream HIP graphs replayed on two streams per step' if stepper.pieces else 'one HIP graph replay per step')
-                           + (' + eager Adam' if world == 1 else ' + eager bucketed all-reduce + Adam'))
+                           + ((' (Adam inside)' if not stepper.pieces else ' + eager Adam') if world == 1 else ' + eager bucketed all-reduce + Adam'))
                 if graphed else 'eager launches',
                 'api': 'PathModel.forward_sweep (whole-sweep entry; per-level drop-in path: --mode dropin)' if args.mode == 'sweep' else 'drop-in per-level model() calls',
             },

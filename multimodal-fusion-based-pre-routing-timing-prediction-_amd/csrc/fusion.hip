@@ -497,10 +497,6 @@ __global__ void __launch_bounds__(256) adam_counted_kernel(float* __restrict__ p
   }
 }
 
-}  // namespace mmft
-
-using namespace mmft;
-
 // out[t][0 .. Da + Db + Dc) = a[t] | b[t] | c[t]; one float4 per thread
 __global__ void __launch_bounds__(256) concat_cols_kernel(const float* __restrict__ a, long long lda, int Da, const float* __restrict__ b,
                                                           long long ldb, int Db, const float* __restrict__ c, long long ldc, int Dc,
@@ -513,6 +509,11 @@ __global__ void __launch_bounds__(256) concat_cols_kernel(const float* __restric
     *reinterpret_cast<f32x4*>(out + t * ldo + col) = *reinterpret_cast<const f32x4*>(src);
   }
 }
+
+}  // namespace mmft
+
+using namespace mmft;
+
 
 extern "C" {
 

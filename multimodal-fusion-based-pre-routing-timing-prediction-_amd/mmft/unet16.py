@@ -463,7 +463,12 @@ class UNet16Fn(torch.autograd.Function):
                     lib.call('mmft_nchw_to_nhwc', rp.x, rp.xn, N, 3, H, W, 3, dev, st)
                     _run_forward(net, rp.xn, pool_mode, packs, rp.T, rp.F, rp.out, geom)
                 rp.fwd = graph
-            rp.x.copy_(x)
+            # the static input copy is skipped when the caller hands in the same, unmodified tensor as last time (the training
+            # loop's resident images): its layout pass then runs on stale-but-identical data
+            # (the tensor object is kept: a new tensor could otherwise reuse the freed address with the same version)
+            if rp.__dict__.get('x_ref') is not x or rp.x_version != x._version:
+                rp.x.copy_(x)
+                rp.x_ref, rp.x_version = x, x._version
             rp.fwd.replay()
             tok = _Token()
             rp.pending = weakref.ref(tok)
