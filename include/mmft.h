@@ -124,10 +124,14 @@ int mmft_mlp2_rows(const float* x1, long long ldx1, const int* rows, int n, cons
  * and the fp32 kernel's weight-panel staging is what remains.  The reverse form (weights_kmajor = 1 of mmft_mlp2_rows) is
  * this entry point fed with the transposed packs: w1_bf16 = bf16(W2g^T) [HD][D2], w2_bf16 = bf16(W1g^T) [K1][HD]. */
 int mmft_pack_bf16(const float* src, long long ld, int R, int C, void* dst_bf16, int transpose, int device, void* stream);
+/* hid_bf16 (this and the level kernels below): `mask` / `hid_out` - fc_cell_neigh's hidden activations HN and their gradients
+ * DHN - are stored as bf16 (ld in elements) although the pointers are typed float*: their consumers round them to bf16 anyway
+ * (weight-gradient MFMA operands, mmft_rows_outer_bf16 with g_bf16 / x_bf16) or look at the sign only (ReLU mask), so no result
+ * changes and 2 KB of traffic per row and direction are saved. */
 int mmft_mlp2_rows_bf16(const float* x1, long long ldx1, const int* rows, int n, const void* w1_bf16, const float* b1,
                         const void* w2_bf16, const float* b2, const float* mask, long long ldmask, float* hid_out,
                         long long ldhid, float* out, long long ldout, int add_act, int relu_out, int K1, int HD, int D2,
-                        const unsigned char* active, int device, void* stream);
+                        const unsigned char* active, int hid_bf16, int device, void* stream);
 /* MMFT_MATH_BF16: the folded gather of one (net level l - 1, cell level l) pair (mmft_pair_fwd_gather) AND the cell level's
  * fc_cell_neigh MLP (mmft_mlp2_rows_bf16, forward form, add_act = 1) in ONE launch: h[net rows] = act(pre + mean h[driver]);
  * A / LSE of the cell rows; h[cell rows] = act(h[cell rows] + W2 relu(W1 A + b1) + b2); hid_out receives the hidden rows.
@@ -136,8 +140,8 @@ int mmft_level_fwd_bf16(float* h, const float* pre, long long ld, int D, const i
                         const int* in_cell_indptr, const int* in_cell_indices, int net_row0, int n_net, const int* cell_rows,
                         int cell_row0, int n_cell, float* A, float* LSE, const void* w1_bf16, const float* b1,
                         const void* w2_bf16, const float* b2, float* hid_out, long long ldhid, int relu,
-                        const unsigned char* active, const int* in_cell_driver, long long alg_bytes, int device,
-                        void* stream);
+                        const unsigned char* active, const int* in_cell_driver, long long alg_bytes, int hid_bf16,
+                        int device, void* stream);
 /* The same launch with the per-edge index chain replaced by a static SLOT table (fan-in <= 4 on every cell row of the level,
  * contiguous row ranges): slots[v] = int[8] = the rows of h to read for v's four in-edges (< 0: no edge) and the rows of
  * `pre` to add (< 0: the edge's value is the h row itself; >= 0: relu(h[hrow] + pre[prow]), the net of level l - 1
@@ -146,7 +150,7 @@ int mmft_level_fwd_bf16(float* h, const float* pre, long long ld, int D, const i
 int mmft_level_fwd_slots(float* h, const float* pre, long long ld, int D, const int* slots, const int* net_driver, int net_row0,
                          int n_net, int cell_row0, int n_cell, float* A, float* LSE, const void* w1_bf16, const float* b1,
                          const void* w2_bf16, const float* b2, float* hid_out, long long ldhid, int relu,
-                         const unsigned char* active, long long alg_bytes, int device, void* stream);
+                         const unsigned char* active, long long alg_bytes, int hid_bf16, int device, void* stream);
 /* Reverse sweep of one (cell level l, net level l + 1) pair in ONE launch (three before: mmft_level_bwd_pull on each level and
  * mmft_mlp2_rows_bf16 in its reverse form) - the autograd mirror of graph.pull + the cell MLP, src/model.py:100-117,138-146,186-187:
  *   net rows w (sinks):   G[w] = relu'(h[w]) ((own[w] ? G[w] : 0) + sum_c DA[c] exp(h[w] - LSE[c]) (1 + h[w] - A[c]))
@@ -166,7 +170,8 @@ int mmft_level_bwd_pair(float* G, const float* h, const float* A, const float* L
                         const unsigned char* own_mask, const int* tiles, int ntiles, const int* out_net_indptr, int sink_shift,
                         const int* cslots, const int* out_cell_indptr, const int* out_cell_indices, float* scratch, int* counters,
                         int relu, int has_mlp, const void* w1_bf16, const void* w2_bf16, const float* mask, long long ldmask,
-                        float* hid_out, long long ldhid, long long alg_bytes, int device, void* stream);
+                        float* hid_out, long long ldhid, long long alg_bytes, int hid_bf16, int device,
+                        void* stream);
 /* MMFT_MATH_BF16: the feature MLPs fc_cell_self / fc_net_self (Linear(fin, 256)-ReLU-Linear(256, 128) over the contiguous node
  * rows row0 .. row0 + n - 1; src/model.py:48-51,66-67,148-153,186-189) WITHOUT a stored hidden tensor.
  *   fwd: out[row] = (relu)(W2 relu(W1 x[row] + b1) + b2); x [.][ldx >= fin] and out [.][ldout] are indexed by NODE id.
@@ -525,7 +530,7 @@ int mmft_concat_cols(const float* a, long long lda, int Da, const float* b, long
 int mmft_rows_outer_supported(int out, int in);
 long long mmft_rows_outer_workspace_bytes(long long rows, int out, int in);
 int mmft_rows_outer_bf16(const float* g, long long ldg, const float* x, long long ldx, float* dw, float* db, long long rows, int out,
-                         int in, int accumulate, float* workspace, long long workspace_bytes, int device, void* stream);
+                         int in, int accumulate, float* workspace, long long workspace_bytes, int g_bf16, int x_bf16, int device, void* stream);
 
 /* ---- bf16-STORAGE layout U-Net (bf16 math mode; BASELINE config B "bf16 storage / fp32 accumulate") --------------------
  * The same layers as above - DoubleConv / Down / Up / OutConv of src/Unet.py:8-82 - with every activation, pre-activation

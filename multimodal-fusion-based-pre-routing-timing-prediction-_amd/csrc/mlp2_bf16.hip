@@ -21,6 +21,25 @@ namespace mmft {
 constexpr int L2_BM = 32, L2_K1 = 128, L2_HD = 256, L2_D2 = 128;
 constexpr int L2_XS = L2_K1 + 8, L2_HS = L2_HD + 8;        // LDS row strides in bf16 elements (multiples of 8)
 
+// Four consecutive columns of a row of the hidden tensors (fc_cell_neigh's hidden activations HN, their gradients DHN): fp32, or
+// - hid16 - bf16 (round to nearest even; `ld` counts elements of the stored type).  Every consumer rounds these values to
+// bf16 anyway (MFMA operands of the weight gradients) or only looks at their sign (the ReLU mask), so the bf16 form changes
+// no result and halves 2 KB of traffic per row and direction.
+__device__ __forceinline__ void hid_store4(float* base, long long off, f32x4 v, int hid16) {
+  if (hid16) {
+    const unsigned lo = pack_bf16(v.x, v.y), hi = pack_bf16(v.z, v.w);
+    *reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned short*>(base) + off) = ((unsigned long long)hi << 32) | lo;
+  } else {
+    *reinterpret_cast<f32x4*>(base + off) = v;
+  }
+}
+__device__ __forceinline__ f32x4 hid_load4(const float* base, long long off, int hid16) {
+  if (!hid16) return *reinterpret_cast<const f32x4*>(base + off);
+  const unsigned long long u = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const unsigned short*>(base) + off);
+  const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+  return f32x4{__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+}
+
 struct Mlp2Bf16Args {
   const float* x1;
   long long ldx1;
@@ -34,6 +53,7 @@ struct Mlp2Bf16Args {
   long long ldmask;
   float* hid_out;
   long long ldhid;
+  int hid16;                   // mask / hid_out hold bf16
   float* out;
   long long ldout;
   int add_act, relu_out;
@@ -104,7 +124,7 @@ __global__ void __launch_bounds__(512) mlp2_rows_bf16_kernel(Mlp2Bf16Args a) {
       const long long row = live ? (long long)a.rows[m0 + m] : 0;
       if (a.mask) {
         f32x4 mk = {0.f, 0.f, 0.f, 0.f};
-        if (live) mk = *reinterpret_cast<const f32x4*>(a.mask + row * a.ldmask + nn);
+        if (live) mk = hid_load4(a.mask, row * a.ldmask + nn, a.hid16);
         v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
         v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
       } else {
@@ -114,7 +134,7 @@ __global__ void __launch_bounds__(512) mlp2_rows_bf16_kernel(Mlp2Bf16Args a) {
       }
       unsigned lo = pack_bf16(v.x, v.y), hi = pack_bf16(v.z, v.w);
       *reinterpret_cast<unsigned long long*>(hs + m * L2_HS + nn) = ((unsigned long long)hi << 32) | lo;
-      if (a.hid_out && live) *reinterpret_cast<f32x4*>(a.hid_out + row * a.ldhid + nn) = v;
+      if (a.hid_out && live) hid_store4(a.hid_out, row * a.ldhid + nn, v, a.hid16);
     }
   __syncthreads();
 
@@ -171,6 +191,7 @@ struct LevelFwdArgs {
   const float *b1, *b2;
   float* hid_out;
   long long ldhid;
+  int hid16;                   // mask / hid_out hold bf16
   int relu;
   const unsigned char* active;
   int cell_tiles;
@@ -270,7 +291,7 @@ __global__ void __launch_bounds__(512) level_fwd_bf16_kernel(LevelFwdArgs a) {
       v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
       unsigned lo = pack_bf16(v.x, v.y), hi = pack_bf16(v.z, v.w);
       *reinterpret_cast<unsigned long long*>(hs + m * L2_HS + nn) = ((unsigned long long)hi << 32) | lo;
-      if (a.hid_out && live_row(m)) *reinterpret_cast<f32x4*>(a.hid_out + (long long)row_of(m) * a.ldhid + nn) = v;
+      if (a.hid_out && live_row(m)) hid_store4(a.hid_out, (long long)row_of(m) * a.ldhid + nn, v, a.hid16);
     }
   __syncthreads();
   f32x4 acc2[RT];
@@ -325,6 +346,7 @@ struct LevelSlotsArgs {
   const float *b1, *b2;
   float* hid_out;
   long long ldhid;
+  int hid16;                   // mask / hid_out hold bf16
   int relu;
   const unsigned char* active;
   int cell_tiles;
@@ -445,7 +467,7 @@ __global__ void __launch_bounds__(512) level_fwd_slots_kernel(LevelSlotsArgs a) 
     hv.z = hv.z > 0.f ? hv.z : 0.f; hv.w = hv.w > 0.f ? hv.w : 0.f;
     const unsigned lo = pack_bf16(hv.x, hv.y), hi = pack_bf16(hv.z, hv.w);
     *reinterpret_cast<unsigned long long*>(hs + r16 * L2_HS + nn) = ((unsigned long long)hi << 32) | lo;
-    if (a.hid_out && elive) *reinterpret_cast<f32x4*>(a.hid_out + (long long)ev * a.ldhid + nn) = hv;
+    if (a.hid_out && elive) hid_store4(a.hid_out, (long long)ev * a.ldhid + nn, hv, a.hid16);
   }
   __syncthreads();
   f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
@@ -518,6 +540,7 @@ struct LevelBwdPairArgs {
   long long ldmask;
   float* hid_out;              // DHN (optional)
   long long ldhid;
+  int hid16;                   // mask / hid_out hold bf16
 };
 
 __global__ void __launch_bounds__(512) level_bwd_pair_kernel(LevelBwdPairArgs a) {
@@ -683,7 +706,7 @@ __global__ void __launch_bounds__(512) level_bwd_pair_kernel(LevelBwdPairArgs a)
     for (int j = 0; j < 2; ++j) {
       mk[i][j] = zero;
       if (r16 + 16 * i < nd)
-        mk[i][j] = *reinterpret_cast<const f32x4*>(a.mask + (long long)(v0 + r16 + 16 * i) * a.ldmask + wave * 32 + j * 16 + q * 4);
+        mk[i][j] = hid_load4(a.mask, (long long)(v0 + r16 + 16 * i) * a.ldmask + wave * 32 + j * 16 + q * 4, a.hid16);
     }
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks)
@@ -713,7 +736,7 @@ __global__ void __launch_bounds__(512) level_bwd_pair_kernel(LevelBwdPairArgs a)
       hvv.z = mk[i][j].z > 0.f ? hvv.z : 0.f; hvv.w = mk[i][j].w > 0.f ? hvv.w : 0.f;
       const unsigned lo = pack_bf16(hvv.x, hvv.y), hi = pack_bf16(hvv.z, hvv.w);
       *reinterpret_cast<unsigned long long*>(hs + row * L2_HS + nn) = ((unsigned long long)hi << 32) | lo;
-      if (a.hid_out && row < nd) *reinterpret_cast<f32x4*>(a.hid_out + (long long)(v0 + row) * a.ldhid + nn) = hvv;
+      if (a.hid_out && row < nd) hid_store4(a.hid_out, (long long)(v0 + row) * a.ldhid + nn, hvv, a.hid16);
     }
   }
   __syncthreads();
@@ -758,8 +781,8 @@ extern "C" int mmft_pack_bf16(const float* src, long long ld, int R, int C, void
 extern "C" int mmft_mlp2_rows_bf16(const float* x1, long long ldx1, const int* rows, int n, const void* w1_bf16,
                                    const float* b1, const void* w2_bf16, const float* b2, const float* mask,
                                    long long ldmask, float* hid_out, long long ldhid, float* out, long long ldout,
-                                   int add_act, int relu_out, int K1, int HD, int D2, const unsigned char* active, int device,
-                                   void* stream) {
+                                   int add_act, int relu_out, int K1, int HD, int D2, const unsigned char* active, int hid_bf16,
+                                   int device, void* stream) {
   MMFT_REQUIRE(x1 && rows && w1_bf16 && w2_bf16 && out, "mlp2_rows_bf16: null pointer");
   if (K1 != L2_K1 || HD != L2_HD || D2 != L2_D2) {
     set_error("mlp2_rows_bf16: only %d -> %d -> %d is fused (got %d -> %d -> %d)", L2_K1, L2_HD, L2_D2, K1, HD, D2);
@@ -774,7 +797,7 @@ extern "C" int mmft_mlp2_rows_bf16(const float* x1, long long ldx1, const int* r
   if (n == 0) return MMFT_OK;
   DeviceGuard dg(device);
   Mlp2Bf16Args a{x1, ldx1, rows, n, (const unsigned short*)w1_bf16, b1, (const unsigned short*)w2_bf16, b2, mask, ldmask,
-                 hid_out, ldhid, out, ldout, add_act, relu_out, active};
+                 hid_out, ldhid, hid_bf16 ? 1 : 0, out, ldout, add_act, relu_out, active};
   const double fl = 2.0 * n * ((double)K1 * HD + (double)HD * D2), by = 4.0 * n * ((double)K1 + 2.0 * HD + 2.0 * D2);
   MMFT_LAUNCH(mask ? "mlp2_rows_bf16_kernel<bwd>" : "mlp2_rows_bf16_kernel<fwd>", fl, by, mlp2_rows_bf16_kernel,
               dim3(cdiv(n, L2_BM)), dim3(512), (hipStream_t)stream, a);
@@ -786,7 +809,7 @@ extern "C" int mmft_level_fwd_bf16(float* h, const float* pre, long long ld, int
                                    int net_row0, int n_net, const int* cell_rows, int cell_row0, int n_cell, float* A,
                                    float* LSE, const void* w1_bf16, const float* b1, const void* w2_bf16, const float* b2,
                                    float* hid_out, long long ldhid, int relu, const unsigned char* active,
-                                   const int* in_cell_driver, long long alg_bytes, int device, void* stream) {
+                                   const int* in_cell_driver, long long alg_bytes, int hid_bf16, int device, void* stream) {
   MMFT_REQUIRE(D == L2_K1, "level_fwd_bf16: D must be %d", L2_K1);
   MMFT_REQUIRE(n_net >= 0 && n_cell >= 0 && net_row0 >= 0 && cell_row0 >= 0, "level_fwd_bf16: negative row count / offset");
   if (n_net + n_cell == 0) return MMFT_OK;
@@ -803,7 +826,7 @@ extern "C" int mmft_level_fwd_bf16(float* h, const float* pre, long long ld, int
   if (net_blocks > 1024) net_blocks = 1024;
   LevelFwdArgs a{h, pre, ld, in_net_indptr, in_net_indices, in_cell_indptr, in_cell_indices, in_cell_driver, net_row0, n_net, cell_rows,
                  cell_row0, n_cell, A, LSE, (const unsigned short*)w1_bf16, (const unsigned short*)w2_bf16, b1, b2, hid_out,
-                 ldhid, relu, active, tiles};
+                 ldhid, hid_bf16 ? 1 : 0, relu, active, tiles};
   const double fl = 2.0 * n_cell * ((double)L2_K1 * L2_HD + (double)L2_HD * L2_D2);
   MMFT_LAUNCH("level_fwd_bf16_kernel", fl, alg_bytes > 0 ? (double)alg_bytes : 0.0, level_fwd_bf16_kernel<LV_BM>,
               dim3(tiles + net_blocks), dim3(512), (hipStream_t)stream, a);
@@ -813,7 +836,7 @@ extern "C" int mmft_level_fwd_bf16(float* h, const float* pre, long long ld, int
 extern "C" int mmft_level_fwd_slots(float* h, const float* pre, long long ld, int D, const int* slots, const int* net_driver,
                                     int net_row0, int n_net, int cell_row0, int n_cell, float* A, float* LSE, const void* w1_bf16,
                                     const float* b1, const void* w2_bf16, const float* b2, float* hid_out, long long ldhid, int relu,
-                                    const unsigned char* active, long long alg_bytes, int device, void* stream) {
+                                    const unsigned char* active, long long alg_bytes, int hid_bf16, int device, void* stream) {
   MMFT_REQUIRE(D == L2_K1, "level_fwd_slots: D must be %d", L2_K1);
   MMFT_REQUIRE(n_net >= 0 && n_cell >= 0 && net_row0 >= 0 && cell_row0 >= 0, "level_fwd_slots: negative row count / offset");
   if (n_net + n_cell == 0) return MMFT_OK;
@@ -825,7 +848,7 @@ extern "C" int mmft_level_fwd_slots(float* h, const float* pre, long long ld, in
   DeviceGuard dg(device);
   const int tiles = cdiv(n_cell, 16), net_tiles = cdiv(n_net, 16);
   LevelSlotsArgs a{h, pre, ld, slots, net_driver, net_row0, n_net, cell_row0, n_cell, A, LSE, (const unsigned short*)w1_bf16,
-                   (const unsigned short*)w2_bf16, b1, b2, hid_out, ldhid, relu, active, tiles};
+                   (const unsigned short*)w2_bf16, b1, b2, hid_out, ldhid, hid_bf16 ? 1 : 0, relu, active, tiles};
   const double fl = 2.0 * n_cell * ((double)L2_K1 * L2_HD + (double)L2_HD * L2_D2);
   MMFT_LAUNCH("level_fwd_slots_kernel", fl, alg_bytes > 0 ? (double)alg_bytes : 0.0, level_fwd_slots_kernel,
               dim3(tiles > net_tiles ? tiles : net_tiles), dim3(512), (hipStream_t)stream, a);
@@ -841,7 +864,7 @@ extern "C" int mmft_level_bwd_pair(float* G, const float* h, const float* A, con
                                    int sink_shift, const int* cslots, const int* out_cell_indptr,
                                    const int* out_cell_indices, float* scratch, int* counters, int relu, int has_mlp,
                                    const void* w1_bf16, const void* w2_bf16, const float* mask, long long ldmask, float* hid_out,
-                                   long long ldhid, long long alg_bytes, int device, void* stream) {
+                                   long long ldhid, long long alg_bytes, int hid_bf16, int device, void* stream) {
   MMFT_REQUIRE(D == L2_K1, "level_bwd_pair: D must be %d", L2_K1);
   MMFT_REQUIRE(ntiles >= 0 && N > 0, "level_bwd_pair: negative tile count");
   if (ntiles == 0) return MMFT_OK;
@@ -856,7 +879,7 @@ extern "C" int mmft_level_bwd_pair(float* G, const float* h, const float* A, con
   DeviceGuard dg(device);
   LevelBwdPairArgs a{G, h, A, LSE, DA, ld, own_mask, tiles, out_net_indptr, sink_shift, cslots, out_cell_indptr, out_cell_indices,
                      scratch, counters, relu, has_mlp, (const unsigned short*)w1_bf16, (const unsigned short*)w2_bf16, mask, ldmask,
-                     hid_out, ldhid};
+                     hid_out, ldhid, hid_bf16 ? 1 : 0};
   MMFT_LAUNCH("level_bwd_pair_kernel", 0.0, alg_bytes > 0 ? (double)alg_bytes : 0.0, level_bwd_pair_kernel, dim3(ntiles), dim3(512),
               (hipStream_t)stream, a);
   return check_launch("level_bwd_pair");

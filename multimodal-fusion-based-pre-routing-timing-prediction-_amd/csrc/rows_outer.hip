@@ -37,7 +37,9 @@ __device__ __forceinline__ ro_bf16x8 ro_tr_pair(const u16* p, int second_off) {
   return __builtin_bit_cast(ro_bf16x8, v);
 }
 
-template <int OUT, int IN>
+// GB / XB: the operand is stored as bf16 (the level MLP's hidden activations / hidden gradients, mlp2_bf16.hip hid16): 8-byte
+// loads go to LDS as they are
+template <int OUT, int IN, bool GB, bool XB>
 __global__ void __launch_bounds__(256) rows_outer_kernel(RowsOuterArgs a) {
   constexpr int PG = OUT + 16, PX = IN + 16;                      // LDS row pitches (elements): 8 * odd dwords -> conflict-free tr reads
   constexpr int MB = OUT / 16, NB = IN / 16, MW = MB / 2, NW = NB / 2;
@@ -57,33 +59,49 @@ __global__ void __launch_bounds__(256) rows_outer_kernel(RowsOuterArgs a) {
 #pragma unroll
     for (int j = 0; j < NW; ++j) acc[i][j] = zero;
   f32x4 cs = zero;                                               // column sums of g: this thread always stages the same 4 columns
-  f32x4 gr[NG], xr[NX];
+  f32x4 gr[NG], xr[NX];                  // fp32 operands: four floats per item; bf16 operands: the 8 bytes in .x / .y
+  auto load4 = [&](const float* base, long long row, long long ld, int col, bool b16) -> f32x4 {
+    if (b16) {
+      const u32x2 v = *reinterpret_cast<const u32x2*>(reinterpret_cast<const u16*>(base) + row * ld + col);
+      return f32x4{__uint_as_float(v.x), __uint_as_float(v.y), 0.f, 0.f};
+    }
+    return *reinterpret_cast<const f32x4*>(base + row * ld + col);
+  };
   auto request = [&](int chunk) {
     const long long r0 = (long long)chunk * RO_KT;
 #pragma unroll
     for (int k = 0; k < NG; ++k) {
       const int it = tid + k * 256, col = (it % (OUT / 4)) * 4, row = it / (OUT / 4);
       const bool ok = r0 + row < a.rows;
-      gr[k] = ok ? *reinterpret_cast<const f32x4*>(a.g + (r0 + row) * a.ldg + col) : zero;
+      gr[k] = ok ? load4(a.g, r0 + row, a.ldg, col, GB) : zero;
     }
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
       const int it = tid + k * 256, col = (it % (IN / 4)) * 4, row = it / (IN / 4);
       const bool ok = r0 + row < a.rows;
-      xr[k] = ok ? *reinterpret_cast<const f32x4*>(a.x + (r0 + row) * a.ldx + col) : zero;
+      xr[k] = ok ? load4(a.x, r0 + row, a.ldx, col, XB) : zero;
     }
   };
   auto deposit = [&]() {
 #pragma unroll
     for (int k = 0; k < NG; ++k) {
       const int it = tid + k * 256, col = (it % (OUT / 4)) * 4, row = it / (OUT / 4);
-      *reinterpret_cast<s16x4*>(gs + row * PG + col) = pack_bf16x4(gr[k]);
-      cs += gr[k];
+      if (GB) {
+        const u32x2 v = {__float_as_uint(gr[k].x), __float_as_uint(gr[k].y)};
+        *reinterpret_cast<u32x2*>(gs + row * PG + col) = v;
+        float f[4];
+        unpack4(v, f);
+        cs += f32x4{f[0], f[1], f[2], f[3]};
+      } else {
+        *reinterpret_cast<s16x4*>(gs + row * PG + col) = pack_bf16x4(gr[k]);
+        cs += gr[k];
+      }
     }
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
       const int it = tid + k * 256, col = (it % (IN / 4)) * 4, row = it / (IN / 4);
-      *reinterpret_cast<s16x4*>(xs + row * PX + col) = pack_bf16x4(xr[k]);
+      if (XB) *reinterpret_cast<u32x2*>(xs + row * PX + col) = u32x2{__float_as_uint(xr[k].x), __float_as_uint(xr[k].y)};
+      else *reinterpret_cast<s16x4*>(xs + row * PX + col) = pack_bf16x4(xr[k]);
     }
   };
   if ((int)blockIdx.x < a.chunks) request(blockIdx.x);
@@ -143,10 +161,11 @@ long long mmft_rows_outer_workspace_bytes(long long rows, int out, int in) {
 }
 
 /* dw [out][in] (+)= g^T x over `rows` rows, db [out] (+)= column sums of g (db may be NULL); g [rows][ldg >= out],
- * x [rows][ldx >= in] fp32, operands rounded to bf16 at staging, fp32 accumulation (bf16 math mode's weight gradient of
+ * x [rows][ldx >= in] fp32 (rounded to bf16 at staging) or - g_bf16 / x_bf16 - stored as bf16 (ld in elements), fp32 accumulation (bf16 math mode's weight gradient of
  * fc_cell_neigh, src/model.py:48-51).  (out, in) in {(128, 256), (256, 128)}. */
 int mmft_rows_outer_bf16(const float* g, long long ldg, const float* x, long long ldx, float* dw, float* db, long long rows, int out,
-                         int in, int accumulate, float* workspace, long long workspace_bytes, int device, void* stream) {
+                         int in, int accumulate, float* workspace, long long workspace_bytes, int g_bf16, int x_bf16, int device,
+                         void* stream) {
   MMFT_REQUIRE(g && x && dw && rows > 0, "rows_outer_bf16: bad arguments");
   MMFT_REQUIRE(mmft_rows_outer_supported(out, in), "rows_outer_bf16: (out, in) must be (128, 256) or (256, 128)");
   MMFT_REQUIRE(ldg >= out && ldx >= in && ldg % 4 == 0 && ldx % 4 == 0 && aligned16(g) && aligned16(x) && aligned16(dw),
@@ -157,11 +176,21 @@ int mmft_rows_outer_bf16(const float* g, long long ldg, const float* x, long lon
   hipStream_t st = (hipStream_t)stream;
   const int chunks = (int)((rows + RO_KT - 1) / RO_KT), grid = rows_outer_grid(chunks);
   RowsOuterArgs a{g, ldg, x, ldx, workspace, rows, chunks};
-  const double fl = 2.0 * rows * out * in, by = 4.0 * rows * (out + in);
-  if (out == 128)
-    MMFT_LAUNCH("rows_outer_kernel<128,256>", fl, by, (rows_outer_kernel<128, 256>), dim3(grid), dim3(256), st, a);
-  else
-    MMFT_LAUNCH("rows_outer_kernel<256,128>", fl, by, (rows_outer_kernel<256, 128>), dim3(grid), dim3(256), st, a);
+  const double fl = 2.0 * rows * out * in, by = (g_bf16 ? 2.0 : 4.0) * rows * out + (x_bf16 ? 2.0 : 4.0) * rows * in;
+#define RO_LAUNCH(O, I, GBV, XBV) \
+  MMFT_LAUNCH("rows_outer_kernel<" #O "," #I ">", fl, by, (rows_outer_kernel<O, I, GBV, XBV>), dim3(grid), dim3(256), st, a)
+  if (out == 128) {
+    if (g_bf16 && x_bf16) RO_LAUNCH(128, 256, true, true);
+    else if (g_bf16) RO_LAUNCH(128, 256, true, false);
+    else if (x_bf16) RO_LAUNCH(128, 256, false, true);
+    else RO_LAUNCH(128, 256, false, false);
+  } else {
+    if (g_bf16 && x_bf16) RO_LAUNCH(256, 128, true, true);
+    else if (g_bf16) RO_LAUNCH(256, 128, true, false);
+    else if (x_bf16) RO_LAUNCH(256, 128, false, true);
+    else RO_LAUNCH(256, 128, false, false);
+  }
+#undef RO_LAUNCH
   int rc = check_launch("rows_outer_bf16");
   if (rc) return rc;
   const long long wel = (long long)out * in;

@@ -36,6 +36,21 @@ def _rows2d(t, name):
     return t
 
 
+def _hid2d(t, name):
+    """A [rows, 256] hidden tensor of the level MLP: fp32, or bf16 where the bf16-mode kernels store it so (sweep.HIDDEN_BF16)."""
+    _chk(t, name, t.dtype if torch.is_tensor(t) and t.dtype == torch.bfloat16 else torch.float32)
+    if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 4:
+        raise ValueError(f'{name}: expected a 2-D tensor with unit inner stride and a row pitch that is a multiple of 4')
+    return t
+
+
+def _same_hid_dtype(*ts):
+    d = {t.dtype for t in ts if t is not None}
+    if len(d) > 1:
+        raise TypeError('the hidden tensors of one call (mask, hid_out) must share their dtype')
+    return int(bool(d) and d.pop() == torch.bfloat16)
+
+
 def strided_rows(t):
     """t itself when the kernels can read it as rows of a wider tensor (2-D, unit inner stride, rows 16-byte aligned - a column
     slice of a concatenation's gradient), else a contiguous copy."""
@@ -126,8 +141,14 @@ ROWS_OUTER = True       # bf16 mode: mmft_rows_outer_bf16 for the fc_cell_neigh 
 def linear_wgrad(g, x, dw=None, gidx=None, xidx=None, rows=None, accumulate=False, db=None, with_bias=False):
     """dw[o][i] (+)= sum_r g[gidx[r]][o] * x[xidx[r]][i]; with_bias (or db given): also db[o] (+)= sum_r g[gidx[r]][o]
     from the same pass, and the pair (dw, db) is returned."""
-    _rows2d(g, 'g'); _rows2d(x, 'x')
+    g16, x16 = g.dtype == torch.bfloat16, x.dtype == torch.bfloat16
+    (_hid2d if g16 else _rows2d)(g, 'g'); (_hid2d if x16 else _rows2d)(x, 'x')
     out, inn = g.shape[1], x.shape[1]
+    if (g16 or x16) and not (ROWS_OUTER and gidx is None and xidx is None and lib.get_math_mode() == 'bf16'
+                             and lib.query('mmft_rows_outer_supported', out, inn)):
+        # a bf16-stored hidden operand outside the row-contraction kernel's shapes: widen it (small / unusual cases only)
+        g, x = (g.float() if g16 else g), (x.float() if x16 else x)
+        g16 = x16 = False
     if rows is None:
         rows = gidx.numel() if gidx is not None else g.shape[0]
     _idx(gidx, 'gidx', rows); _idx(xidx, 'xidx', rows)
@@ -147,13 +168,13 @@ def linear_wgrad(g, x, dw=None, gidx=None, xidx=None, rows=None, accumulate=Fals
         _chk(db, 'db')
         if db.numel() != out or not db.is_contiguous():
             raise ValueError('linear_wgrad: db shape')
-    if ROWS_OUTER and gidx is None and xidx is None and rows >= 4096 and dw.is_contiguous() and g.stride(0) % 4 == 0 and \
+    if ROWS_OUTER and gidx is None and xidx is None and (rows >= 4096 or g16 or x16) and dw.is_contiguous() and g.stride(0) % 4 == 0 and \
             x.stride(0) % 4 == 0 and lib.get_math_mode() == 'bf16' and lib.query('mmft_rows_outer_supported', out, inn):
         # bf16 mode, plain row ranges, the 128 x 256 / 256 x 128 products of fc_cell_neigh: transposed LDS reads instead of
         # the engine's in-register transposes
         ws = lib.workspace(g.device, lib.query('mmft_rows_outer_workspace_bytes', rows, out, inn))
         lib.call('mmft_rows_outer_bf16', g, g.stride(0), x, x.stride(0), dw, db if want_db else None, rows, out, inn, int(accumulate),
-                 ws, ws.numel() * 4, dev, st)
+                 ws, ws.numel() * 4, int(g16), int(x16), dev, st)
         return (dw, db) if want_db else dw
     if want_db:
         ws = lib.workspace(g.device, lib.query('mmft_linear_wgrad_bias_workspace_bytes', rows, out, inn))
@@ -242,13 +263,14 @@ def mlp2_rows_bf16(x1, rows, w1p, b1, w2p, b2, out, mask=None, hid_out=None, add
         raise ValueError('mlp2_rows_bf16: 128 -> 256 -> 128 over node-indexed buffers')
     for t, nm in ((mask, 'mask'), (hid_out, 'hid_out')):
         if t is not None:
-            _rows2d(t, nm)
+            _hid2d(t, nm)
             if t.shape[1] != 256 or t.shape[0] != x1.shape[0]:
                 raise ValueError(f'mlp2_rows_bf16: {nm} must be [rows of x1, 256]')
     dev, st = lib.stream_args(x1)
     lib.call('mmft_mlp2_rows_bf16', x1, x1.stride(0), rows, rows.numel(), w1p, b1, w2p, b2, mask,
              mask.stride(0) if mask is not None else 0, hid_out, hid_out.stride(0) if hid_out is not None else 0, out,
-             out.stride(0), int(add_act), int(relu_out), 128, 256, 128, _active(active, x1.shape[0]), dev, st)
+             out.stride(0), int(add_act), int(relu_out), 128, 256, 128, _active(active, x1.shape[0]), _same_hid_dtype(mask, hid_out),
+             dev, st)
     return out
 
 
@@ -268,13 +290,13 @@ def level_fwd_bf16(h, pre, in_net, in_cell, net_range, cell_rows, A, LSE, w1p, b
     for t, nm, shape in ((w1p, 'w1p', (256, 128)), (w2p, 'w2p', (128, 256))):
         if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.bfloat16 and tuple(t.shape) == shape and t.is_contiguous()):
             raise ValueError(f'level_fwd_bf16: {nm} must be a contiguous bf16 CUDA tensor of shape {shape}')
-    _rows2d(hid_out, 'hid_out')
+    _hid2d(hid_out, 'hid_out')
     if hid_out.shape != (N, 256):
         raise ValueError('level_fwd_bf16: hid_out must be [N, 256]')
     dev, st = lib.stream_args(h)
     lib.call('mmft_level_fwd_bf16', h, pre, h.stride(0), 128, in_net[0], in_net[1], in_cell[0], in_cell[1], nrow0, nn, ct, crow0,
              nc, A, LSE, w1p, b1, w2p, b2, hid_out, hid_out.stride(0), int(relu), _active(active, N),
-             _edge_drivers(in_cell_driver, in_cell[1]), int(alg_bytes), dev, st)
+             _edge_drivers(in_cell_driver, in_cell[1]), int(alg_bytes), _same_hid_dtype(hid_out), dev, st)
 
 
 def level_fwd_slots(h, pre, slots, net_driver, net_range, cell_range, A, LSE, w1p, b1, w2p, b2, hid_out, relu=True, active=None,
@@ -297,12 +319,12 @@ def level_fwd_slots(h, pre, slots, net_driver, net_range, cell_range, A, LSE, w1
     for t, nm, shape in ((w1p, 'w1p', (256, 128)), (w2p, 'w2p', (128, 256))):
         if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.bfloat16 and tuple(t.shape) == shape and t.is_contiguous()):
             raise ValueError(f'level_fwd_slots: {nm} must be a contiguous bf16 CUDA tensor of shape {shape}')
-    _rows2d(hid_out, 'hid_out')
+    _hid2d(hid_out, 'hid_out')
     if hid_out.shape != (N, 256):
         raise ValueError('level_fwd_slots: hid_out must be [N, 256]')
     dev, st = lib.stream_args(h)
     lib.call('mmft_level_fwd_slots', h, pre, h.stride(0), 128, slots, net_driver, nrow0, nn, crow0, nc, A, LSE, w1p, b1, w2p, b2,
-             hid_out, hid_out.stride(0), int(relu), _active(active, N), int(alg_bytes), dev, st)
+             hid_out, hid_out.stride(0), int(relu), _active(active, N), int(alg_bytes), _same_hid_dtype(hid_out), dev, st)
 
 
 def level_bwd_pair(G, h, A, LSE, DA, own, tiles, ntiles, out_net_indptr, sink_shift, cslots, out_cell, scratch, counters, w1p, w2p,
@@ -342,14 +364,14 @@ def level_bwd_pair(G, h, A, LSE, DA, own, tiles, ntiles, out_net_indptr, sink_sh
         for t, nm in ((HN, 'HN'), (DHN, 'DHN')):
             if t is None and nm == 'DHN':
                 continue
-            _rows2d(t, nm)
+            _hid2d(t, nm)
             if tuple(t.shape) != (N, 256):
                 raise ValueError(f'level_bwd_pair: {nm} must be [N, 256]')
     dev, st = lib.stream_args(h)
     lib.call('mmft_level_bwd_pair', G, h, A, LSE, DA, h.stride(0), 128, N, own, tiles, int(ntiles), out_net_indptr, int(sink_shift),
              cslots, out_cell[0], out_cell[1], scratch, counters, int(relu), int(bool(has_mlp)), w1p if has_mlp else None, w2p if has_mlp else None, HN if has_mlp else None,
              HN.stride(0) if has_mlp else 0, DHN if has_mlp else None, DHN.stride(0) if (has_mlp and DHN is not None) else 0,
-             int(alg_bytes), dev, st)
+             int(alg_bytes), _same_hid_dtype(HN, DHN) if has_mlp else 0, dev, st)
 
 
 def mlp2_feat_fusable(fin, HD, D2):

@@ -68,12 +68,12 @@ class SweepState:
         self.target_order = None
         self.targets_unique = None
 
-    def _buf(self, name, width):
+    def _buf(self, name, width, dtype=torch.float32):
         b = self._bufs.get(name)
         if b is None:
             # zeros, not empty: with fan-in-cone pruning rows outside the cone are never written, yet batched GEMMs read
             # them next to zero gradients - they must hold finite values
-            b = torch.zeros((self.N, width), dtype=torch.float32, device=self.h.device)
+            b = torch.zeros((self.N, width), dtype=dtype, device=self.h.device)
             self._bufs[name] = b
         return b
 
@@ -196,7 +196,7 @@ def _cell_neigh_bwd(st, rows, w1g, w2g, keep_dhn=False):
         dhn_out = None
         if keep_dhn:
             if st.DHN is None:
-                st.DHN = st._buf('DHN', st.Hd)
+                st.DHN = st._buf('DHN16', st.Hd, torch.bfloat16) if getattr(st, 'hid16', False) else st._buf('DHN', st.Hd)
             dhn_out = st.DHN
         if st.wpack is not None:
             ops.mlp2_rows_bf16(st.G, rows, st.wpack[2], None, st.wpack[3], None, st.DA, mask=st.HN, hid_out=dhn_out,
@@ -462,6 +462,7 @@ EDGE_DRIVERS = True                 # folded gather: per-edge driver table (3-de
 FEAT_MLP_NO_HIDDEN = True           # bf16 mode: fc_cell_self / fc_net_self as one kernel each way, hidden activations recomputed
 FUSE_LEVEL_FWD = True               # bf16 mode: folded gather + fused MLP of a level pair in one launch (mmft_level_fwd_bf16)
 LEVEL_SLOTS = True                  # ... in its slot-table form where the level allows it (mmft_level_fwd_slots: fan-in <= 4, ranges)
+HIDDEN_BF16 = True                  # bf16 mode: fc_cell_neigh's hidden activations / hidden gradients stored as bf16
 LEVEL_BWD_PAIRS = True              # reverse sweep: one launch per (cell level, net level above it) pair where the numbering
                                     # allows it (PinGraph.level_bwd_pairs; mmft_level_bwd_pair)
 FOLD_LEVELS = True                  # folded forward chain (one gather per (net, cell) level PAIR) when the graph allows it
@@ -484,6 +485,12 @@ class SweepFn(torch.autograd.Function):
                         ops.pack_bf16(w1g, transpose=True))
         r0 = level_rows[0]
         rc2 = _cat_rows(st, lambda l: l % 2 == 0 and l > 0)
+        # bf16 mode on range-numbered graphs: fc_cell_neigh's hidden activations and their gradients are STORED as bf16 - every
+        # consumer rounds them to bf16 anyway (MFMA operands of the weight gradients) or reads the sign only (ReLU mask); only
+        # the first layer's bias gradient now sums the rounded hidden gradients instead of the fp32 ones
+        st.hid16 = bool(HIDDEN_BF16 and st.wpack is not None and isinstance(rc2, tuple) and st.attn is None)
+        st.HN = st._buf('HN16', st.Hd, torch.bfloat16) if st.hid16 else st._buf('HN', st.Hd)
+        st.DHN = None
         rn = _cat_rows(st, lambda l: l % 2 == 1)
         st.row_sets = (_cat_rows(st, lambda l: l % 2 == 0), rn, rc2)
         r0s = _cat_rows(st, lambda l: l == 0) if r0.numel() else None
@@ -533,7 +540,7 @@ class SweepFn(torch.autograd.Function):
                     crow = fold[level_id]['range'] or level_rows[level_id]
                 fused = has_cell and st.wpack is not None and fold[level_id]['heavy_in'] is None and FUSE_LEVEL_FWD
                 level_bytes = (meta_n['bytes_mean'] if meta_n else 0) + (meta_c['bytes_softmax'] if meta_c else 0) + \
-                    (level_rows[level_id].numel() * (8 * st.D + 4 * st.Hd) if (meta_c and has_cell) else 0)
+                    (level_rows[level_id].numel() * (8 * st.D + (2 if st.hid16 else 4) * st.Hd) if (meta_c and has_cell) else 0)
                 if fused and slot_tabs is not None and fold[level_id]['range'] is not None and slot_tabs[2][level_id] <= 4 and \
                         (fold[net_l]['range'] is not None or not fold[net_l]['n']):
                     # ... with the static slot table instead of the per-edge index chain, net rows inside the cell workgroups
@@ -548,7 +555,7 @@ class SweepFn(torch.autograd.Function):
                                        # gather bytes of the pair + what the MLP part must move per cell row: h read and
                                        # written (2 x 4 D) and the hidden row kept for the reverse sweep (4 Hd)
                                        alg_bytes=(meta_n['bytes_mean'] if meta_n else 0) + (meta_c['bytes_softmax'] if meta_c else 0)
-                                       + (level_rows[level_id].numel() * (8 * st.D + 4 * st.Hd) if meta_c else 0))
+                                       + (level_rows[level_id].numel() * (8 * st.D + (2 if st.hid16 else 4) * st.Hd) if meta_c else 0))
                     continue
                 ops.pair_fwd_gather(st.h, st.PRE, in_net, in_cell, fold[net_l]['range'] or (0, 0), crow, st.A, st.LSE,
                                     relu=st.relu, heavy=fold[level_id]['heavy_in'] if has_cell else None, active=st.active,
@@ -609,7 +616,7 @@ class SweepFn(torch.autograd.Function):
         if pairs is not None:
             cslots, plist, pscratch, pcounters = pairs
             if st.DHN is None:
-                st.DHN = st._buf('DHN', st.Hd)
+                st.DHN = st._buf('DHN16', st.Hd, torch.bfloat16) if getattr(st, 'hid16', False) else st._buf('DHN', st.Hd)
         for level_id, rows in reversed(st.levels):
             if level_id in paired:
                 continue
@@ -622,7 +629,7 @@ class SweepFn(torch.autograd.Function):
                     mc = st.level_meta[cell_l] if st.level_meta else None
                     mn = st.level_meta[cell_l + 1] if (st.level_meta and cell_l + 1 < len(st.level_meta)) else None
                     nb = (mc['bytes_pull'] if mc else 0) + (mn['bytes_pull'] if mn else 0) + \
-                        (pr['n_cell'] * (8 * st.D + 8 * st.Hd) if cell_l > 0 else 0)
+                        (pr['n_cell'] * (8 * st.D + (4 if st.hid16 else 8) * st.Hd) if cell_l > 0 else 0)
                     ops.level_bwd_pair(st.G, st.h, st.A, st.LSE, st.DA, own, pr['tiles'], pr['ntiles'], out_net[0], pr['sink_shift'],
                                        cslots, out_cell, pscratch, pcounters, st.wpack[2], st.wpack[3], st.HN, st.DHN, relu=st.relu, has_mlp=cell_l > 0,
                                        alg_bytes=nb)

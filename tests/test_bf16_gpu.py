@@ -448,6 +448,38 @@ def test_full_size_config_b_in_bf16_mode(dev):
     assert rel_err(a[3], f[3]) > 1e-6                      # ... and bf16 mode really was a different arithmetic
 
 
+@pytest.mark.parametrize('out,inn,rows,g16,x16', [(128, 256, 5000, False, True), (256, 128, 4099, True, False), (128, 256, 777, True, True)])
+def test_rows_outer_with_bf16_stored_operands(dev, out, inn, rows, g16, x16):
+    """The same contraction with an operand STORED as bf16 (the level MLP's hidden activations / hidden gradients,
+    sweep.HIDDEN_BF16): bitwise the result of the fp32-stored operand, which the kernel rounds to the same bf16 while staging -
+    except the bias gradient of a bf16-stored g, which sums the rounded values; padded row pitch; and the fallback that widens
+    the operand when the row-contraction kernel is switched off."""
+    g = rnd(rows, out, seed=41)
+    x = rnd(rows, inn, seed=42)
+    gd = torch.zeros(rows, out + 8, device=dev)[:, :out].copy_(g.to(dev))
+    xd = torch.zeros(rows, inn + 8, device=dev)[:, :inn].copy_(x.to(dev))
+    g_in = torch.zeros(rows, out + 8, device=dev, dtype=torch.bfloat16)[:, :out].copy_(gd) if g16 else gd
+    x_in = torch.zeros(rows, inn + 8, device=dev, dtype=torch.bfloat16)[:, :inn].copy_(xd) if x16 else xd
+    ops.ROWS_OUTER = True
+    dw_ref, db_ref = ops.linear_wgrad(bf(g).to(dev) if rows < 4096 else gd, bf(x).to(dev) if rows < 4096 else xd, with_bias=True)
+    lib.prof_reset()
+    lib.prof_enable(True)
+    dw, db = ops.linear_wgrad(g_in, x_in, with_bias=True)
+    torch.cuda.synchronize()
+    lib.prof_enable(False)
+    assert any(r['name'].startswith('rows_outer_kernel') for r in lib.prof_report())
+    if rows >= 4096:
+        assert torch.equal(dw, dw_ref)
+    assert rel_err(dw, bf(g).double().T @ bf(x).double()) < TOL
+    assert rel_err(db, (bf(g) if g16 else g).double().sum(0)) < 1e-5
+    ops.ROWS_OUTER = False
+    try:
+        dw3, db3 = ops.linear_wgrad(g_in, x_in, with_bias=True)
+    finally:
+        ops.ROWS_OUTER = True
+    assert rel_err(dw3, dw) < 1e-3 and rel_err(db3, db) < 1e-5
+
+
 @pytest.mark.parametrize('out,inn,rows,ld_pad', [(128, 256, 5000, 0), (256, 128, 4099, 8), (128, 256, 70001, 0)])
 @pytest.mark.parametrize('representable', [True, False])
 def test_rows_outer_weight_gradient(dev, out, inn, rows, ld_pad, representable):

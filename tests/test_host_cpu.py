@@ -278,3 +278,43 @@ def test_bench_sec8d_formula():
     assert r['fwd']['launches_per_step'] == 5 and r['bwd']['launches_per_step'] == 12
     assert abs(r['fwd']['achieved_gbs'] - r['fwd']['bytes_per_step'] / 0.1e-3 / 1e9) < 1e-6
     assert abs(r['fwd']['frac_of_hbm_peak'] - r['fwd']['achieved_gbs'] / bench.PEAK_HBM_GBS) < 1e-12
+
+
+def test_every_call_site_matches_the_header():
+    """Static check: each `lib.call('mmft_x', ...)` / `lib.query(...)` in the package, the tools, the tests and bench.py passes
+    exactly as many arguments as include/mmft.h declares for that entry point (ctypes would only notice on a GPU box)."""
+    import ast
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, 'include', 'mmft.h')).read()
+    protos = {}
+    for m in re.finditer(r'\b(?:int|long long|const char\*)\s+(mmft_\w+)\s*\(([^;]*?)\)\s*;', hdr, re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ('', 'void') else len(args.split(','))
+    files = glob.glob(os.path.join(root, 'multimodal-fusion-based-pre-routing-timing-prediction-_amd', '**', '*.py'), recursive=True)
+    files += glob.glob(os.path.join(root, 'tests', '*.py')) + glob.glob(os.path.join(root, 'tools', '*.py')) + [os.path.join(root, 'bench.py')]
+    checked, bad = 0, []
+    for f in files:
+        for node in ast.walk(ast.parse(open(f).read())):
+            if not (isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr in ('call', 'query') and node.args
+                    and isinstance(node.args[0], ast.Constant) and isinstance(node.args[0].value, str) and node.args[0].value.startswith('mmft_')):
+                continue
+            name, n, unknown = node.args[0].value, 0, False
+            for a in node.args[1:]:
+                if isinstance(a, ast.Starred):
+                    if isinstance(a.value, ast.Call) and getattr(a.value.func, 'attr', '') == 'stream_args':
+                        n += 2                                  # (device, stream)
+                    else:
+                        unknown = True
+                else:
+                    n += 1
+            if unknown:
+                continue
+            checked += 1
+            if name not in protos:
+                bad.append((name, 'not declared', f, node.lineno))
+            elif protos[name] != n:
+                bad.append((name, protos[name], n, f, node.lineno))
+    assert checked > 100 and not bad, bad
