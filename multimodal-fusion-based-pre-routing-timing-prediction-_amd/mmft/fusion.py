@@ -89,6 +89,20 @@ class PathMasks:
             self.bnd_code = torch.from_numpy(codes[order].astype(np.int32)).to(device)
 
     @staticmethod
+    def from_sparse_coo(path_masks, device):
+        """From the reference's own container: the sparse COO `(num_paths, P)` tensor of ones that
+        src/verilog_parser_asap7.py:1353-1368 builds and the training loop indexes (src/train.py:500).  Zero entries are
+        dropped, duplicates merged; rows keep their order, columns ascend inside a row."""
+        sp = path_masks.coalesce().cpu()
+        idx, val = sp.indices().numpy(), sp.values().numpy()
+        keep = val != 0
+        rows, cols = idx[0][keep].astype(np.int64), idx[1][keep].astype(np.int64)      # coalesce() sorts by (row, column)
+        n, P = int(sp.shape[0]), int(sp.shape[1])
+        indptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.bincount(rows, minlength=n), out=indptr[1:])
+        return PathMasks(indptr, cols, P, device)
+
+    @staticmethod
     def batch(masks):
         P, dev = masks[0].P, masks[0].indptr.device
         ip, cols, rd, off = [np.zeros(1, dtype=np.int64)], [], [], 0

@@ -318,3 +318,27 @@ def test_every_call_site_matches_the_header():
             elif protos[name] != n:
                 bad.append((name, protos[name], n, f, node.lineno))
     assert checked > 100 and not bad, bad
+
+
+def test_path_masks_from_the_reference_sparse_tensor():
+    """PathMasks.from_sparse_coo: the reference keeps path masks as a sparse COO tensor of int64 ones
+    (src/verilog_parser_asap7.py:1353-1368); the CSR the kernels take has the same rows, ascending columns, no zeros."""
+    import numpy as np
+    import torch
+    from mmft.fusion import PathMasks
+    rng = np.random.default_rng(3)
+    n, P = 37, 256
+    dense = (rng.random((n, P)) < 0.07).astype(np.int64)
+    dense[5] = 0                                                      # an empty row
+    r, c = np.nonzero(dense)
+    perm = rng.permutation(r.shape[0])                                # COO entries in arbitrary order, one explicit zero
+    idx = torch.tensor(np.stack([np.concatenate([r[perm], [5]]), np.concatenate([c[perm], [9]])]))
+    sp = torch.sparse_coo_tensor(idx, torch.cat([torch.ones(r.shape[0], dtype=torch.int64), torch.zeros(1, dtype=torch.int64)]), (n, P))
+    m = PathMasks.from_sparse_coo(sp, 'cpu')
+    assert m.num_paths == n and m.P == P
+    back = np.zeros((n, P), dtype=np.int64)
+    for i in range(n):
+        cols = m.host_cols[m.host_indptr[i]:m.host_indptr[i + 1]]
+        assert (np.diff(cols) > 0).all()
+        back[i, cols] = 1
+    assert (back == dense).all()
