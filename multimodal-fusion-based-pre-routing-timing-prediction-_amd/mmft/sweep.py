@@ -361,7 +361,25 @@ def level_forward(conv, graph, cur_nodes, targets, level_id):
         del seen[:]
         if SPECULATE and spec is not None and not graph.__dict__.get('_spec_disabled') and not torch.is_tensor(cur_nodes) \
                 and _same_list(cur_nodes, spec[0]):
-            st, token = _run_sweep(conv, graph, spec, None)
+            dev_ = graph.ndata['h'].device
+            # (only with gradient sinks on every parameter - FlatAdam: parameters that accumulate through autograd's own
+            # AccumulateGrad nodes, created under the caller's stream, would be fed from another stream)
+            sinks_ = all(gradsink.of(p) is not None for k in _MLP_KEYS for p in _mlp2_params(getattr(conv, k)))
+            if SPEC_SIDE_STREAM and sinks_ and not torch.cuda.is_current_stream_capturing():
+                # the whole sweep runs on a stream of its own: its autograd node then runs its backward there as well, next
+                # to the U-Net's backward on the caller's stream (the caller's loop has one stream; inside a captured step
+                # TrainStep forks the streams itself).  The caller's stream waits for the sweep right away - every later level
+                # call reads h.
+                side = graph.__dict__.get('_spec_stream')
+                if side is None or side.device != dev_:
+                    side = graph.__dict__['_spec_stream'] = torch.cuda.Stream(device=dev_)
+                cur_ = torch.cuda.current_stream(dev_)
+                side.wait_stream(cur_)
+                with torch.cuda.stream(side):
+                    st, token = _run_sweep(conv, graph, spec, None)
+                cur_.wait_stream(side)
+            else:
+                st, token = _run_sweep(conv, graph, spec, None)
             st.spec_lists, st.spec_token, st.spec_tix, st.next_level = spec, token, [], 0
             spec_active = True
     else:
@@ -462,6 +480,7 @@ EDGE_DRIVERS = True                 # folded gather: per-edge driver table (3-de
 FEAT_MLP_NO_HIDDEN = True           # bf16 mode: fc_cell_self / fc_net_self as one kernel each way, hidden activations recomputed
 FUSE_LEVEL_FWD = True               # bf16 mode: folded gather + fused MLP of a level pair in one launch (mmft_level_fwd_bf16)
 LEVEL_SLOTS = True                  # ... in its slot-table form where the level allows it (mmft_level_fwd_slots: fan-in <= 4, ranges)
+SPEC_SIDE_STREAM = True             # drop-in loop: the speculative whole sweep (and with it its backward) on a stream of its own
 HIDDEN_BF16 = True                  # bf16 mode: fc_cell_neigh's hidden activations / hidden gradients stored as bf16
 LEVEL_BWD_PAIRS = True              # reverse sweep: one launch per (cell level, net level above it) pair where the numbering
                                     # allows it (PinGraph.level_bwd_pairs; mmft_level_bwd_pair)
