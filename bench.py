@@ -453,16 +453,19 @@ def main():
             try:
                 pm3, cnn3 = build_models(map_size=designs[0].map_size, device=dev, seed=9294)
                 ts3 = TrainStep(pm3, cnn3, designs, dev, world_size=1, mode='dropin', dense_path_map=dense, keep_grads=False)
-                sched = HISTORY[:(6 if dense else 13)]
-                for ids in sched[:3]:
+                # 5 untimed steps (level-by-level first sweep, graph captures of the U-Net, first replays) + 20 timed ones for
+                # the handle form; the dense form (10 x slower) 3 + 3
+                nwarm, ntimed = (3, 3) if dense else (5, 20)
+                sched = (HISTORY * (1 + (nwarm + ntimed) // max(len(HISTORY), 1)))[:nwarm + ntimed]
+                for ids in sched[:nwarm]:
                     ts3.step(ids)
                 torch.cuda.synchronize()
                 t3 = time.perf_counter()
-                for ids in sched[3:]:
+                for ids in sched[nwarm:]:
                     ts3.step(ids)
                 torch.cuda.synchronize()
-                dropin[key] = (time.perf_counter() - t3) / max(len(sched) - 3, 1) * 1e3
-                log(f'{key}: {dropin[key]:.2f} ms ({len(sched) - 3} steps)')
+                dropin[key] = (time.perf_counter() - t3) / max(len(sched) - nwarm, 1) * 1e3
+                log(f'{key}: {dropin[key]:.2f} ms ({len(sched) - nwarm} steps)')
                 del ts3, pm3, cnn3
                 torch.cuda.empty_cache()
             except Exception as e:                       # noqa: BLE001 - an extra measurement must not cost the bench line
