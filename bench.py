@@ -453,6 +453,8 @@ def main():
             try:
                 pm3, cnn3 = build_models(map_size=designs[0].map_size, device=dev, seed=9294)
                 ts3 = TrainStep(pm3, cnn3, designs, dev, world_size=1, mode='dropin', dense_path_map=dense, keep_grads=False)
+                gc.collect()
+                gc.freeze()      # ... including this step object's own level lists
                 # 5 untimed steps (level-by-level first sweep, graph captures of the U-Net, first replays) + 20 timed ones for
                 # the handle form; the dense form (10 x slower) 3 + 3
                 nwarm, ntimed = (3, 3) if dense else (5, 20)
@@ -461,8 +463,16 @@ def main():
                     ts3.step(ids)
                 torch.cuda.synchronize()
                 t3 = time.perf_counter()
-                for ids in sched[nwarm:]:
-                    ts3.step(ids)
+                if os.environ.get('MMFT_DROPIN_TRACE'):
+                    per = []
+                    for ids in sched[nwarm:]:
+                        t4 = time.perf_counter()
+                        ts3.step(ids)
+                        per.append((time.perf_counter() - t4) * 1e3)
+                    log(f'{key}: host ms per step ' + ' '.join(f'{x:.1f}' for x in per))
+                else:
+                    for ids in sched[nwarm:]:
+                        ts3.step(ids)
                 torch.cuda.synchronize()
                 dropin[key] = (time.perf_counter() - t3) / max(len(sched) - nwarm, 1) * 1e3
                 log(f'{key}: {dropin[key]:.2f} ms ({len(sched) - nwarm} steps)')

@@ -107,6 +107,7 @@ def query(name, *args):
 
 
 _workspace = {}
+_retired = []
 
 
 def workspace(device, nbytes):
@@ -119,6 +120,11 @@ def workspace(device, nbytes):
     buf = _workspace.get(key)
     need = max(int(nbytes), 1 << 20)
     if buf is None or buf.numel() * 4 < need:
+        if buf is not None:
+            # a captured HIP graph may hold this buffer's address (the whole-step graph, the U-Net's replay graphs): an
+            # outgrown buffer is retired, never handed back to the allocator for somebody else's tensor
+            _retired.append(buf)
+            need = max(need, 2 * buf.numel() * 4)          # geometric growth bounds what the retired ones add up to
         buf = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
         _workspace[key] = buf
     return buf

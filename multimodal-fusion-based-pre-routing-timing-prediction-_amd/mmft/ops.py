@@ -51,6 +51,20 @@ def _same_hid_dtype(*ts):
     return int(bool(d) and d.pop() == torch.bfloat16)
 
 
+def _launch(name, args):
+    """lib.call, returning the argument list with tensors replaced by their addresses: a caller whose tensors are persistent
+    (the sweep's buffers and static tables) keeps the list and repeats the launch with `relaunch`, skipping this wrapper's
+    checks - the per-level kernels of the drop-in loop are issued eagerly, 63 times per step, and the checks cost more
+    host time than the launch."""
+    lib.call(name, *args)
+    return [a.data_ptr() if torch.is_tensor(a) else a for a in args]
+
+
+def relaunch(name, raw, dev, stream):
+    """Repeat a launch recorded by `_launch` on the given stream (the last two arguments of every entry point)."""
+    lib.call(name, *raw[:-2], dev, stream)
+
+
 def strided_rows(t):
     """t itself when the kernels can read it as rows of a wider tensor (2-D, unit inner stride, rows 16-byte aligned - a column
     slice of a concatenation's gradient), else a contiguous copy."""
@@ -243,11 +257,15 @@ def mlp2_rows(x1, rows, w1, b1, w2, b2, out, kmajor=False, mask=None, hid_out=No
     return out
 
 
-def pack_bf16(w, transpose=False):
+def pack_bf16(w, transpose=False, out=None):
     """bf16 copy of a small fp32 matrix ([R, C] -> [R, C], or [C, R] with transpose) for the pre-packed bf16 kernels."""
     _rows2d(w, 'w')
     R, C = w.shape
-    out = torch.empty((C, R) if transpose else (R, C), dtype=torch.bfloat16, device=w.device)
+    shape = (C, R) if transpose else (R, C)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.bfloat16, device=w.device)
+    elif not (out.is_cuda and out.dtype == torch.bfloat16 and tuple(out.shape) == shape and out.is_contiguous()):
+        raise ValueError(f'pack_bf16: out must be a contiguous bf16 CUDA tensor of shape {shape}')
     dev, st = lib.stream_args(w)
     lib.call('mmft_pack_bf16', w, w.stride(0), R, C, out, int(transpose), dev, st)
     return out
@@ -323,8 +341,9 @@ def level_fwd_slots(h, pre, slots, net_driver, net_range, cell_range, A, LSE, w1
     if hid_out.shape != (N, 256):
         raise ValueError('level_fwd_slots: hid_out must be [N, 256]')
     dev, st = lib.stream_args(h)
-    lib.call('mmft_level_fwd_slots', h, pre, h.stride(0), 128, slots, net_driver, nrow0, nn, crow0, nc, A, LSE, w1p, b1, w2p, b2,
-             hid_out, hid_out.stride(0), int(relu), _active(active, N), int(alg_bytes), _same_hid_dtype(hid_out), dev, st)
+    return _launch('mmft_level_fwd_slots', [h, pre, h.stride(0), 128, slots, net_driver, nrow0, nn, crow0, nc, A, LSE, w1p, b1, w2p, b2,
+                                            hid_out, hid_out.stride(0), int(relu), _active(active, N), int(alg_bytes),
+                                            _same_hid_dtype(hid_out), dev, st])
 
 
 def level_bwd_pair(G, h, A, LSE, DA, own, tiles, ntiles, out_net_indptr, sink_shift, cslots, out_cell, scratch, counters, w1p, w2p,
@@ -368,10 +387,12 @@ def level_bwd_pair(G, h, A, LSE, DA, own, tiles, ntiles, out_net_indptr, sink_sh
             if tuple(t.shape) != (N, 256):
                 raise ValueError(f'level_bwd_pair: {nm} must be [N, 256]')
     dev, st = lib.stream_args(h)
-    lib.call('mmft_level_bwd_pair', G, h, A, LSE, DA, h.stride(0), 128, N, own, tiles, int(ntiles), out_net_indptr, int(sink_shift),
-             cslots, out_cell[0], out_cell[1], scratch, counters, int(relu), int(bool(has_mlp)), w1p if has_mlp else None, w2p if has_mlp else None, HN if has_mlp else None,
-             HN.stride(0) if has_mlp else 0, DHN if has_mlp else None, DHN.stride(0) if (has_mlp and DHN is not None) else 0,
-             int(alg_bytes), _same_hid_dtype(HN, DHN) if has_mlp else 0, dev, st)
+    return _launch('mmft_level_bwd_pair', [G, h, A, LSE, DA, h.stride(0), 128, N, own, tiles, int(ntiles), out_net_indptr, int(sink_shift),
+                                           cslots, out_cell[0], out_cell[1], scratch, counters, int(relu), int(bool(has_mlp)),
+                                           w1p if has_mlp else None, w2p if has_mlp else None, HN if has_mlp else None,
+                                           HN.stride(0) if has_mlp else 0, DHN if has_mlp else None,
+                                           DHN.stride(0) if (has_mlp and DHN is not None) else 0, int(alg_bytes),
+                                           _same_hid_dtype(HN, DHN) if has_mlp else 0, dev, st])
 
 
 def mlp2_feat_fusable(fin, HD, D2):

@@ -480,6 +480,7 @@ EDGE_DRIVERS = True                 # folded gather: per-edge driver table (3-de
 FEAT_MLP_NO_HIDDEN = True           # bf16 mode: fc_cell_self / fc_net_self as one kernel each way, hidden activations recomputed
 FUSE_LEVEL_FWD = True               # bf16 mode: folded gather + fused MLP of a level pair in one launch (mmft_level_fwd_bf16)
 LEVEL_SLOTS = True                  # ... in its slot-table form where the level allows it (mmft_level_fwd_slots: fan-in <= 4, ranges)
+RECORD_LAUNCHES = True              # eager sweeps: the per-level kernels' validated argument lists are kept and re-issued (ops.relaunch)
 SPEC_SIDE_STREAM = True             # drop-in loop: the speculative whole sweep (and with it its backward) on a stream of its own
 HIDDEN_BF16 = True                  # bf16 mode: fc_cell_neigh's hidden activations / hidden gradients stored as bf16
 LEVEL_BWD_PAIRS = True              # reverse sweep: one launch per (cell level, net level above it) pair where the numbering
@@ -500,8 +501,13 @@ class SweepFn(torch.autograd.Function):
         st.wpack = None
         if lib.get_math_mode() == 'bf16' and ops.mlp2_fusable(st.D, st.Hd, st.D):
             # the level chain's fused MLP takes its weights pre-packed as bf16 (forward: W1, W2; reverse: W2^T, W1^T)
-            st.wpack = (ops.pack_bf16(w1g), ops.pack_bf16(w2g), ops.pack_bf16(w2g, transpose=True),
-                        ops.pack_bf16(w1g, transpose=True))
+            # (static buffers per graph: their addresses are part of the recorded launches below)
+            wp = st._bufs.get('wpack')
+            if wp is None or wp[0].device != st.h.device:
+                mk = lambda *shape: torch.empty(shape, dtype=torch.bfloat16, device=st.h.device)
+                wp = st._bufs['wpack'] = (mk(st.Hd, st.D), mk(st.D, st.Hd), mk(st.Hd, st.D), mk(st.D, st.Hd))
+            st.wpack = (ops.pack_bf16(w1g, out=wp[0]), ops.pack_bf16(w2g, out=wp[1]), ops.pack_bf16(w2g, transpose=True, out=wp[2]),
+                        ops.pack_bf16(w1g, transpose=True, out=wp[3]))
         r0 = level_rows[0]
         rc2 = _cat_rows(st, lambda l: l % 2 == 0 and l > 0)
         # bf16 mode on range-numbered graphs: fc_cell_neigh's hidden activations and their gradients are STORED as bf16 - every
@@ -510,6 +516,17 @@ class SweepFn(torch.autograd.Function):
         st.hid16 = bool(HIDDEN_BF16 and st.wpack is not None and isinstance(rc2, tuple) and st.attn is None)
         st.HN = st._buf('HN16', st.Hd, torch.bfloat16) if st.hid16 else st._buf('HN', st.Hd)
         st.DHN = None
+        # Recorded launches of the two per-level kernels (ops.relaunch): valid while the sweep's buffers (persistent per graph),
+        # the static tables of these level lists, the parameters and h are the same objects at the same addresses
+        sig = (id(getattr(st, 'level_lists', None)), st.hid16, st.relu, st.h.data_ptr(), st.active is None,
+               tuple(p.data_ptr() for p in P))
+        prep = st._bufs.get('prep')
+        if not RECORD_LAUNCHES or getattr(st, 'level_lists', None) is None or st.active is not None:
+            prep = None
+        elif prep is None or prep['sig'] != sig:
+            prep = st._bufs['prep'] = dict(sig=sig, lists=st.level_lists, calls={})
+        st.prep = prep
+        dev_, stream_ = lib.stream_args(st.h)
         rn = _cat_rows(st, lambda l: l % 2 == 1)
         st.row_sets = (_cat_rows(st, lambda l: l % 2 == 0), rn, rc2)
         r0s = _cat_rows(st, lambda l: l == 0) if r0.numel() else None
@@ -563,9 +580,15 @@ class SweepFn(torch.autograd.Function):
                 if fused and slot_tabs is not None and fold[level_id]['range'] is not None and slot_tabs[2][level_id] <= 4 and \
                         (fold[net_l]['range'] is not None or not fold[net_l]['n']):
                     # ... with the static slot table instead of the per-edge index chain, net rows inside the cell workgroups
-                    ops.level_fwd_slots(st.h, st.PRE, slot_tabs[0], slot_tabs[1], fold[net_l]['range'] or (0, 0), fold[level_id]['range'],
-                                        st.A, st.LSE, st.wpack[0], b1g, st.wpack[1], b2g, st.HN, relu=st.relu, active=st.active,
-                                        alg_bytes=level_bytes)
+                    rec = prep['calls'].get(('f', level_id)) if prep is not None else None
+                    if rec is not None:
+                        ops.relaunch('mmft_level_fwd_slots', rec, dev_, stream_)
+                        continue
+                    rec = ops.level_fwd_slots(st.h, st.PRE, slot_tabs[0], slot_tabs[1], fold[net_l]['range'] or (0, 0), fold[level_id]['range'],
+                                              st.A, st.LSE, st.wpack[0], b1g, st.wpack[1], b2g, st.HN, relu=st.relu, active=st.active,
+                                              alg_bytes=level_bytes)
+                    if prep is not None:
+                        prep['calls'][('f', level_id)] = rec
                     continue
                 if fused:
                     # bf16 mode: gather + fc_cell_neigh of the pair in ONE launch
@@ -632,6 +655,8 @@ class SweepFn(torch.autograd.Function):
                 and getattr(st, 'level_lists', None) is not None:
             pairs = g.level_bwd_pairs(st.level_lists)
         paired = set()
+        prep = getattr(st, 'prep', None) if fast else None
+        dev_b, stream_b = lib.stream_args(st.h)
         if pairs is not None:
             cslots, plist, pscratch, pcounters = pairs
             if st.DHN is None:
@@ -649,9 +674,15 @@ class SweepFn(torch.autograd.Function):
                     mn = st.level_meta[cell_l + 1] if (st.level_meta and cell_l + 1 < len(st.level_meta)) else None
                     nb = (mc['bytes_pull'] if mc else 0) + (mn['bytes_pull'] if mn else 0) + \
                         (pr['n_cell'] * (8 * st.D + (4 if st.hid16 else 8) * st.Hd) if cell_l > 0 else 0)
-                    ops.level_bwd_pair(st.G, st.h, st.A, st.LSE, st.DA, own, pr['tiles'], pr['ntiles'], out_net[0], pr['sink_shift'],
-                                       cslots, out_cell, pscratch, pcounters, st.wpack[2], st.wpack[3], st.HN, st.DHN, relu=st.relu, has_mlp=cell_l > 0,
-                                       alg_bytes=nb)
+                    rec = prep['calls'].get(('b', cell_l)) if prep is not None else None
+                    if rec is not None:
+                        ops.relaunch('mmft_level_bwd_pair', rec, dev_b, stream_b)
+                        continue
+                    rec = ops.level_bwd_pair(st.G, st.h, st.A, st.LSE, st.DA, own, pr['tiles'], pr['ntiles'], out_net[0], pr['sink_shift'],
+                                             cslots, out_cell, pscratch, pcounters, st.wpack[2], st.wpack[3], st.HN, st.DHN, relu=st.relu,
+                                             has_mlp=cell_l > 0, alg_bytes=nb)
+                    if prep is not None:
+                        prep['calls'][('b', cell_l)] = rec
                     continue
             if not rows.numel():
                 continue
