@@ -789,3 +789,36 @@ def test_dropin_unet_graph_replay_in_bf16_mode(dev):
             finally:
                 unet16.REPLAY = True
     assert out[True][0] == out[False][0] and torch.equal(out[True][1], out[False][1])
+
+
+def test_dropin_sweep_opt_in_paths_equal_the_default(dev):
+    """The opt-in forms of the speculative drop-in sweep - on a stream of its own (sweep.SPEC_SIDE_STREAM: the engine joins it
+    at the end of backward through the sweep node's anchor leaf), replayed from captured HIP graphs (sweep.SWEEP_REPLAY),
+    without the recorded launches (sweep.RECORD_LAUNCHES = False) - train exactly like the default: the same losses and
+    parameters after six steps, bit for bit."""
+    from mmft import lib, sweep as S
+    from mmft.synth import synth_design
+    from mmft.train import build_models, TrainStep
+    designs = [synth_design(N=6000, L=12, tile=64, seed=420 + i, end_frac=0.2) for i in range(2)]
+    rng = np.random.default_rng(7)
+    batches = [[rng.permutation(d.num_paths)[:60] for d in designs] for _ in range(6)]
+    out = {}
+    saved = (S.SPEC_SIDE_STREAM, S.SWEEP_REPLAY, S.RECORD_LAUNCHES)
+    try:
+        with lib.math_mode('bf16'):
+            for name, flags in (('default', saved), ('side', (True, False, True)), ('replay', (True, True, True)),
+                                ('plain', (False, False, False))):
+                S.SPEC_SIDE_STREAM, S.SWEEP_REPLAY, S.RECORD_LAUNCHES = flags
+                pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=11)
+                ts = TrainStep(pmodel, cnn, designs, dev, mode='dropin')
+                losses = [float(ts.step(ids)[0]) for ids in batches]
+                torch.cuda.synchronize()
+                rp = ts.batch.graph.__dict__.get('_sweep_bufs', {}).get('replay')
+                if name == 'replay':
+                    assert rp is not None and rp.fwd is not None and rp.bwd is not None     # the graphs were captured and used
+                out[name] = (losses, ts.optim.flat_param.clone())
+    finally:
+        S.SPEC_SIDE_STREAM, S.SWEEP_REPLAY, S.RECORD_LAUNCHES = saved
+    for name in ('side', 'replay', 'plain'):
+        assert out[name][0] == out['default'][0], name
+        assert torch.equal(out[name][1], out['default'][1]), name
