@@ -303,10 +303,32 @@ __global__ void __launch_bounds__(1024) mse_kernel(const float* __restrict__ pre
   __shared__ double red[1024];
   double s = 0.0;
   float inv = 2.0f / (float)n;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    float d = pred[i] - (idx ? target[(long long)idx[i] * ld] : target[i]);
-    s += (double)d * (double)d;
-    if (grad) grad[i] = d * inv;
+  // one workgroup between the forward and the backward pass of BOTH streams: four elements per thread are requested together
+  // (index, then gathered target and prediction) and consumed in the old order - the sum is bit for bit the serial loop's
+  for (int i0 = threadIdx.x; i0 < n; i0 += 4 * (int)blockDim.x) {
+    int ii[4];
+    float p[4], t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k * (int)blockDim.x;
+      ii[k] = (i < n && idx) ? idx[i] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k * (int)blockDim.x;
+      const bool ok = i < n;
+      t[k] = ok ? (idx ? target[(long long)ii[k] * ld] : target[i]) : 0.f;
+      p[k] = ok ? pred[i] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k * (int)blockDim.x;
+      if (i < n) {
+        const float d = p[k] - t[k];
+        s += (double)d * (double)d;
+        if (grad) grad[i] = d * inv;
+      }
+    }
   }
   red[threadIdx.x] = s;
   __syncthreads();

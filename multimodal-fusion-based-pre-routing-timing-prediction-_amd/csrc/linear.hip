@@ -240,10 +240,12 @@ int launch_slab_reduce_batch(const SlabSeg* segs, int n, hipStream_t st) {
 // ---------------------------------------------------------------- column sums (bias gradients)
 // stage 1: block = 16 row lanes x 16 column groups (4 columns each) over a strip of rows -> partial[strip][cols];
 // stage 2 = slab_reduce (fixed order)
-constexpr int COLSUM_STRIP = 1024;
+// The strip shrinks for short inputs: 10 800 head rows in strips of 1024 were 22 workgroups walking 64 rows per lane (24 us);
+// strips of 128 rows are 170 workgroups (the launch is latency, not bandwidth).
+static inline int colsum_strip(int rows) { return rows <= (1 << 16) ? 128 : 1024; }
 __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ g, const int* __restrict__ idx,
                                                              long long ld, int rows, int cols,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial, int COLSUM_STRIP) {
   __shared__ float part[16][65];
   const int rl = threadIdx.x >> 4, cg = threadIdx.x & 15;
   const int c0 = blockIdx.x * 64 + cg * 4;
@@ -280,7 +282,7 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __rest
 }
 
 static inline int colsum_blocks(int rows) {
-  int nb = cdiv(rows, COLSUM_STRIP);
+  int nb = cdiv(rows, colsum_strip(rows));
   return nb < 1 ? 1 : nb;
 }
 
@@ -529,7 +531,7 @@ int mmft_colsum(const float* g, const int* idx, long long ld, int rows, int cols
   int nb = colsum_blocks(rows);
   MMFT_REQUIRE(workspace && workspace_bytes >= (long long)nb * cols * 4, "colsum: workspace too small");
   MMFT_LAUNCH("colsum_partial_kernel", 0.0, 4.0 * rows * cols, colsum_partial_kernel, dim3(cdiv(cols, 64), nb), dim3(256), st,
-              g, idx, ld, rows, cols, workspace);
+              g, idx, ld, rows, cols, workspace, colsum_strip(rows));
   int rc = check_launch("colsum_partial");
   if (rc) return rc;
   return launch_slab_reduce(workspace, nb, cols, out, accumulate, st);
