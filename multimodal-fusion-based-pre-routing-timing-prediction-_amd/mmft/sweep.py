@@ -742,7 +742,7 @@ class SweepFn(torch.autograd.Function):
         st.bwd_active = False
         # `anchor` (see _run_sweep): a defined gradient, so that its AccumulateGrad node - a function without outputs, living on
         # this node's stream - makes the engine join that stream with the caller's at the end of backward()
-        ga = st.h.new_zeros(1) if ctx.needs_input_grad[4] else None
+        ga = st.h.new_empty(1) if ctx.needs_input_grad[4] else None      # its value is never read: no fill launch
         return (None, None, None, dc, ga, *grads)
 
     @staticmethod
@@ -845,7 +845,7 @@ def _run_sweep(conv, graph, level_nodes, tix, target_order=None, targets_unique=
         # The sweep may run on a stream of its own and, with gradient sinks, returns no gradient to any leaf: nothing would
         # tell the engine to join that stream when backward() ends (it joins the streams of functions WITHOUT outputs, i.e.
         # of AccumulateGrad nodes that ran).  A one-element leaf created here, on the sweep's stream, is that node.
-        anchor = st.h.new_zeros(1, requires_grad=True)
+        anchor = st.h.new_empty(1, requires_grad=True)                   # (neither its value nor its gradient is ever read)
         return st, SweepFn.apply(st, level_rows, tix, c12, anchor, *st.params)
     with torch.no_grad():
         return st, SweepFn.apply(st, level_rows, tix, c12, None)
