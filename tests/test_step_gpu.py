@@ -451,3 +451,29 @@ def test_cone_pruning_inside_the_training_step(dev):
                           {k: v.clone() for k, v in cnn.state_dict().items()}, dtype=torch.float64)
     h_o, tl, _ = orc.forward(d, R.design_csr(d), batches[0][0])
     assert tl == res[True][5] and rel_err(res[True][0], h_o) < 1e-4
+
+
+@pytest.mark.parametrize('graphed', [False, True])
+def test_adam_clearing_consumed_gradients_equals_zero_grad(dev, graphed):
+    """TrainStep(keep_grads=False) - the bench's setting: the fused Adam launch clears the gradients it consumed instead of a
+    zero_grad() fill per step - trains bit for bit like the default, eagerly and replayed from the whole-step graph; .grad
+    reads zero after step()."""
+    from mmft import lib
+    from mmft.synth import synth_design
+    from mmft.train import build_models, TrainStep, GraphedTrainStep
+    designs = [synth_design(N=3000, L=10, tile=64, seed=510 + i, end_frac=0.25) for i in range(2)]
+    rng = np.random.default_rng(9)
+    batches = [[rng.permutation(d.num_paths)[:50] for d in designs] for _ in range(5)]
+    out = {}
+    with lib.math_mode('bf16'):
+        for keep in (True, False):
+            pmodel, cnn = build_models(map_size=designs[0].map_size, device=dev, seed=13)
+            ts = TrainStep(pmodel, cnn, designs, dev, keep_grads=keep)
+            stepper = GraphedTrainStep(ts, batches[0]) if graphed else ts
+            losses = [float(stepper.step(ids)[0]) for ids in batches]
+            torch.cuda.synchronize()
+            if not keep:
+                assert float(ts.optim.flat_grad.abs().max()) == 0.0
+            out[keep] = (losses, ts.optim.flat_param.clone())
+    assert out[True][0] == out[False][0]
+    assert torch.equal(out[True][1], out[False][1])
