@@ -14,6 +14,7 @@
 //     operands from transposed bf16 copies of the tile in LDS); one slab per workgroup, summed in a fixed order.
 // Lane layouts are those of mlp2_bf16.hip: A = weights / transposed tiles (lane = output feature, 8 consecutive k),
 // B = row tiles (lane = row or feature, 8 consecutive k), D[m][n] at lane (n = lane & 15, q = lane >> 4) = rows 4q..4q+3.
+#include <stdlib.h>
 #include "gemm_bf16.h"
 #include "tr_read.h"
 
@@ -332,9 +333,15 @@ constexpr int feat_bwd_lds() {
 }
 
 static inline long long feat_slab(int fin) { return (long long)MF_HD * fin + MF_HD + (long long)MF_D2 * MF_HD + MF_D2; }
+// One workgroup per CU (256 VGPRs) - on 192 of the 256 CUs: the two launches close the reverse sweep on its side stream while
+// the U-Net's backward, the stream that finishes last, still runs on the main one; a grid that takes every CU for 2 x 118 us
+// stalls it.  Measured on the replayed config-B step (ms): 256 -> 3.37, 224 -> 3.28, 192 -> 3.23, 160 -> 3.26, 128 -> 3.29.
+// MMFT_FEAT_BWD_GRID overrides (read once).
 static inline int feat_bwd_grid(int n) {
   int tiles = cdiv(n, 32);
-  return tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256;
+  static int cap = getenv("MMFT_FEAT_BWD_GRID") ? atoi(getenv("MMFT_FEAT_BWD_GRID")) : 192;
+  if (cap < 1) cap = 1;
+  return tiles < cap ? (tiles < 1 ? 1 : tiles) : cap;
 }
 
 }  // namespace mmft
