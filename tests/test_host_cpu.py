@@ -342,3 +342,57 @@ def test_path_masks_from_the_reference_sparse_tensor():
         assert (np.diff(cols) > 0).all()
         back[i, cols] = 1
     assert (back == dense).all()
+
+
+def test_level_bwd_pair_tables_cover_every_driver_and_sink_once():
+    """PinGraph.level_bwd_pairs (host side of the paired reverse kernel): after DesignBatch's numbering the out-net edge list of a
+    cell level IS the id range of the net level above it; the tile table covers every driver exactly once (whole, or as
+    consecutive parts of at most BWD_PAIR_PART sinks with one counter and a scratch row per part), every sink exactly once,
+    whole-driver tiles hold at most BWD_PAIR_TILE_DRIVERS drivers and BWD_PAIR_TILE_SINKS sinks; the consumer slot table
+    reproduces the out-cell CSR (first four in slots, the rest through the CSR position in slot 3)."""
+    import numpy as np
+    from mmft.pingraph import PinGraph
+    from mmft.synth import synth_design
+    from mmft.train import DesignBatch
+    designs = [synth_design(N=5000, L=10, tile=32, seed=730 + i, end_frac=0.2, fanin='irregular') for i in range(2)]
+    b = DesignBatch(designs, 'cpu')
+    g = b.graph
+    cslots, pairs, scratch, counters = g.level_bwd_pairs(b.level_nodes)
+    assert all(p is not None for p in pairs)
+    optr, oidx = g.csr_host('out', 'net')
+    cptr, cidx = g.csr_host('out', 'cell')
+    cs = cslots.numpy()
+    for u in np.random.default_rng(0).integers(0, g.number_of_nodes(), 400):
+        cons = cidx[cptr[u]:cptr[u + 1]]
+        if len(cons) <= 4:
+            assert list(cs[u][:len(cons)]) == list(cons) and (cs[u][len(cons):] == -1).all()
+        else:
+            assert list(cs[u][:3]) == list(cons[:3]) and cs[u][3] == -2 - (cptr[u] + 3)
+    heavy_seen = 0
+    for l, pr in zip(range(0, len(b.level_nodes), 2), pairs):
+        row0, n = int(b.level_nodes[l][0]), len(b.level_nodes[l])
+        assert b.level_nodes[l] == list(range(row0, row0 + n))
+        e0, e1 = int(optr[row0]), int(optr[row0 + n])
+        if pr['n_net']:
+            assert list(oidx[e0:e1]) == list(range(e0 + pr['sink_shift'], e1 + pr['sink_shift']))
+        drivers, sinks = np.zeros(n, int), np.zeros(e1 - e0, int)
+        parts_of = {}
+        for v0, nd, part, parts, srow, cidx_, s0, s1 in pr['tiles'].numpy().tolist():
+            assert 1 <= nd <= PinGraph.BWD_PAIR_TILE_DRIVERS and e0 <= s0 <= s1 <= e1
+            sinks[s0 - e0:s1 - e0] += 1
+            if parts == 0:
+                drivers[v0 - row0:v0 - row0 + nd] += 1
+                assert (s0, s1) == (int(optr[v0]), int(optr[v0 + nd])) and (s1 - s0 <= PinGraph.BWD_PAIR_TILE_SINKS)
+            else:
+                heavy_seen += 1
+                assert nd == 1 and 0 <= part < parts and s1 - s0 <= PinGraph.BWD_PAIR_PART
+                assert srow + parts <= scratch.shape[0] and cidx_ < counters.numel()
+                parts_of.setdefault((v0, parts, srow, cidx_), []).append((part, s0, s1))
+        for (v0, parts, _, _), lst in parts_of.items():
+            lst.sort()
+            assert [p for p, _, _ in lst] == list(range(parts))
+            assert lst[0][1] == int(optr[v0]) and lst[-1][2] == int(optr[v0 + 1]) and all(a[2] == c[1] for a, c in zip(lst, lst[1:]))
+            assert int(optr[v0 + 1] - optr[v0]) > PinGraph.BWD_PAIR_TILE_SINKS
+            drivers[v0 - row0] += 1
+        assert (drivers == 1).all() and (sinks == 1).all()
+    assert heavy_seen > 0
