@@ -13,6 +13,7 @@
 //     (conflict-light ds_read_b128, 26 KB in all), two barriers in the whole kernel;
 //   * 8 waves per 32-row tile: wave w owns hidden columns [32w, 32w + 32) and output columns [16w, 16w + 16).
 // The reverse form (weights_kmajor in the fp32 kernel) is the same kernel fed with the transposed packs.
+#include <stdlib.h>
 #include "gemm_bf16.h"
 #include "fold_gather.h"
 
@@ -352,8 +353,11 @@ struct LevelSlotsArgs {
   int cell_tiles;
 };
 
+template <int RB>
 __global__ void __launch_bounds__(512) level_fwd_slots_kernel(LevelSlotsArgs a) {
-  constexpr int BM = 16;
+  // RB row blocks of 16 cell rows per workgroup: thread group g gathers rows g, g + 16, ..; with RB = 2 half as many workgroups
+  // fetch the 128 KB of packed weights (64 MB of L2 traffic per launch at RB = 1)
+  constexpr int BM = 16 * RB;
   __shared__ __attribute__((aligned(16))) unsigned short xs[BM * L2_XS];
   __shared__ __attribute__((aligned(16))) unsigned short hs[BM * L2_HS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -362,67 +366,87 @@ __global__ void __launch_bounds__(512) level_fwd_slots_kernel(LevelSlotsArgs a) 
   const bool has_cell = b < a.cell_tiles;
   const int m0 = b * BM;
   // ---- requests whose addresses are known now
-  const int nrow = b * BM + gr, u = a.net_row0 + nrow;
-  const bool net_ok = nrow < a.n_net && (!a.active || a.active[u]);
-  int nd = -1;
-  f32x4 npre = {0.f, 0.f, 0.f, 0.f};
-  if (net_ok) {
-    nd = a.net_drv[u];
-    npre = *reinterpret_cast<const f32x4*>(a.pre + (long long)u * a.ld + gc);
-  }
-  const int v = a.cell_row0 + m0 + gr;
-  const bool live = has_cell && m0 + gr < a.n_cell && (!a.active || a.active[v]);
-  int hrow[4] = {-1, -1, -1, -1}, prow[4] = {-1, -1, -1, -1};
-  if (live) {
-    const int4 s0 = *reinterpret_cast<const int4*>(a.slots + (long long)v * 8);
-    const int4 s1 = *reinterpret_cast<const int4*>(a.slots + (long long)v * 8 + 4);
-    hrow[0] = s0.x; hrow[1] = s0.y; hrow[2] = s0.z; hrow[3] = s0.w;
-    prow[0] = s1.x; prow[1] = s1.y; prow[2] = s1.z; prow[3] = s1.w;
+  int nd[RB];
+  f32x4 npre[RB];
+  bool net_ok[RB], live[RB];
+  int hrow[RB][4], prow[RB][4];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int nrow = b * BM + gr + 16 * rb, u = a.net_row0 + nrow;
+    net_ok[rb] = nrow < a.n_net && (!a.active || a.active[u]);
+    nd[rb] = -1;
+    npre[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (net_ok[rb]) {
+      nd[rb] = a.net_drv[u];
+      npre[rb] = *reinterpret_cast<const f32x4*>(a.pre + (long long)u * a.ld + gc);
+    }
+    const int v = a.cell_row0 + m0 + gr + 16 * rb;
+    live[rb] = has_cell && m0 + gr + 16 * rb < a.n_cell && (!a.active || a.active[v]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hrow[rb][k] = prow[rb][k] = -1;
+    if (live[rb]) {
+      const int4 s0 = *reinterpret_cast<const int4*>(a.slots + (long long)v * 8);
+      const int4 s1 = *reinterpret_cast<const int4*>(a.slots + (long long)v * 8 + 4);
+      hrow[rb][0] = s0.x; hrow[rb][1] = s0.y; hrow[rb][2] = s0.z; hrow[rb][3] = s0.w;
+      prow[rb][0] = s1.x; prow[rb][1] = s1.y; prow[rb][2] = s1.z; prow[rb][3] = s1.w;
+    }
   }
   bf16x8 w1f[2][4], w2f[8];
-  // epilogue-2 operand of this lane: row m0 + r16, output features wave * 16 + 4 q ..
-  const int ev = a.cell_row0 + m0 + r16;
-  const bool elive = has_cell && m0 + r16 < a.n_cell && (!a.active || a.active[ev]);
-  f32x4 hold = {0.f, 0.f, 0.f, 0.f};
+  // epilogue-2 operand of this lane: rows m0 + r16 (+ 16), output features wave * 16 + 4 q ..
+  bool elive[RB];
+  f32x4 hold[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int ev = a.cell_row0 + m0 + r16 + 16 * rb;
+    elive[rb] = has_cell && m0 + r16 + 16 * rb < a.n_cell && (!a.active || a.active[ev]);
+    hold[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   if (has_cell) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
         w1f[j][ks] = *reinterpret_cast<const bf16x8*>(a.w1 + (long long)(wave * 32 + j * 16 + r16) * L2_K1 + ks * 32 + q * 8);
-    if (elive) hold = *reinterpret_cast<const f32x4*>(a.h + (long long)ev * a.ld + wave * 16 + q * 4);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+      if (elive[rb]) hold[rb] = *reinterpret_cast<const f32x4*>(a.h + (long long)(a.cell_row0 + m0 + r16 + 16 * rb) * a.ld + wave * 16 + q * 4);
   }
-  // ---- net row of level l - 1: h[u] = act(PRE[u] + h[driver])   (mean over ONE in-edge = the driver's row itself)
-  if (net_ok) {
-    f32x4 hd = {0.f, 0.f, 0.f, 0.f};
-    if (nd >= 0) hd = *reinterpret_cast<const f32x4*>(a.h + (long long)nd * a.ld + gc);
-    *reinterpret_cast<f32x4*>(a.h + (long long)u * a.ld + gc) = fg_finish_net(hd, npre, a.relu);
-  }
+  // ---- net rows of level l - 1: h[u] = act(PRE[u] + h[driver])   (mean over ONE in-edge = the driver's row itself)
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+    if (net_ok[rb]) {
+      const int u = a.net_row0 + b * BM + gr + 16 * rb;
+      f32x4 hd = {0.f, 0.f, 0.f, 0.f};
+      if (nd[rb] >= 0) hd = *reinterpret_cast<const f32x4*>(a.h + (long long)nd[rb] * a.ld + gc);
+      *reinterpret_cast<f32x4*>(a.h + (long long)u * a.ld + gc) = fg_finish_net(hd, npre[rb], a.relu);
+    }
   if (!has_cell) return;
   if (a.active) {
     int any = 0;
     if (tid < BM) any = (m0 + tid < a.n_cell && a.active[a.cell_row0 + m0 + tid]) ? 1 : 0;
     if (!__syncthreads_or(any)) return;
   }
-  // ---- gather of the thread's (row, channel group): the four slots requested together, consumed in edge order
-  {
+  // ---- gather of the thread's (row, channel group)s: the four slots requested together, consumed in edge order
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int v = a.cell_row0 + m0 + gr + 16 * rb;
     f32x4 av = {0.f, 0.f, 0.f, 0.f};
-    if (live) {
-      const int h0 = hrow[0] >= 0 ? hrow[0] : v;             // an empty row still issues (and drops) loads of valid rows
+    if (live[rb]) {
+      const int h0 = hrow[rb][0] >= 0 ? hrow[rb][0] : v;             // an empty row still issues (and drops) loads of valid rows
       f32x4 xa[4], xp[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        xa[k] = *reinterpret_cast<const f32x4*>(a.h + (long long)(hrow[k] >= 0 ? hrow[k] : h0) * a.ld + gc);
-        xp[k] = *reinterpret_cast<const f32x4*>(a.pre + (long long)(prow[k] >= 0 ? prow[k] : a.net_row0) * a.ld + gc);
+        xa[k] = *reinterpret_cast<const f32x4*>(a.h + (long long)(hrow[rb][k] >= 0 ? hrow[rb][k] : h0) * a.ld + gc);
+        xp[k] = *reinterpret_cast<const f32x4*>(a.pre + (long long)(prow[rb][k] >= 0 ? prow[rb][k] : a.net_row0) * a.ld + gc);
       }
       SoftAccT<true> sa;
       sa.init();
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const f32x4 x = prow[k] >= 0 ? fg_finish_net(xa[k], xp[k], a.relu) : xa[k];
+        const f32x4 x = prow[rb][k] >= 0 ? fg_finish_net(xa[k], xp[k], a.relu) : xa[k];
         SoftAccT<true> nx = sa;
         nx.add(x);
-        const bool ok = hrow[k] >= 0;
+        const bool ok = hrow[rb][k] >= 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           sa.mx[j] = ok ? nx.mx[j] : sa.mx[j];
@@ -431,7 +455,7 @@ __global__ void __launch_bounds__(512) level_fwd_slots_kernel(LevelSlotsArgs a) 
         }
       }
       f32x4 lv = {0.f, 0.f, 0.f, 0.f};
-      if (hrow[0] >= 0) {
+      if (hrow[rb][0] >= 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           av[j] = sa.acc[j] / sa.s[j];
@@ -442,50 +466,61 @@ __global__ void __launch_bounds__(512) level_fwd_slots_kernel(LevelSlotsArgs a) 
       *reinterpret_cast<f32x4*>(a.LSE + (long long)v * a.ld + gc) = lv;
     }
     const unsigned lo = pack_bf16(av.x, av.y), hi = pack_bf16(av.z, av.w);
-    *reinterpret_cast<unsigned long long*>(xs + gr * L2_XS + gc) = ((unsigned long long)hi << 32) | lo;
+    *reinterpret_cast<unsigned long long*>(xs + (gr + 16 * rb) * L2_XS + gc) = ((unsigned long long)hi << 32) | lo;
   }
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks)
     w2f[ks] = *reinterpret_cast<const bf16x8*>(a.w2 + (long long)(wave * 16 + r16) * L2_HD + ks * 32 + q * 8);
   __syncthreads();
-  // ---- phase 1 / epilogue 1 / phase 2 / epilogue 2: as level_fwd_bf16_kernel<16>
-  f32x4 acc1[2];
+  // ---- phase 1 / epilogue 1 / phase 2 / epilogue 2: as level_fwd_bf16_kernel<16>, per row block
+  f32x4 acc1[RB][2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) acc1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc1[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xs + r16 * L2_XS + ks * 32 + q * 8);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[j][ks], xf, acc1[j], 0, 0, 0);
-  }
+    for (int rb = 0; rb < RB; ++rb) {
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xs + (r16 + 16 * rb) * L2_XS + ks * 32 + q * 8);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int nn = wave * 32 + j * 16 + q * 4;
-    f32x4 hv = acc1[j];
-    if (a.b1) hv += *reinterpret_cast<const f32x4*>(a.b1 + nn);
-    hv.x = hv.x > 0.f ? hv.x : 0.f; hv.y = hv.y > 0.f ? hv.y : 0.f;
-    hv.z = hv.z > 0.f ? hv.z : 0.f; hv.w = hv.w > 0.f ? hv.w : 0.f;
-    const unsigned lo = pack_bf16(hv.x, hv.y), hi = pack_bf16(hv.z, hv.w);
-    *reinterpret_cast<unsigned long long*>(hs + r16 * L2_HS + nn) = ((unsigned long long)hi << 32) | lo;
-    if (a.hid_out && elive) hid_store4(a.hid_out, (long long)ev * a.ldhid + nn, hv, a.hid16);
-  }
-  __syncthreads();
-  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hs + r16 * L2_HS + ks * 32 + q * 8);
-    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[ks], hf, acc2, 0, 0, 0);
-  }
-  if (elive) {
-    const int nn = wave * 16 + q * 4;
-    f32x4 o = acc2;
-    if (a.b2) o += *reinterpret_cast<const f32x4*>(a.b2 + nn);
-    o += hold;
-    if (a.relu) {
-      o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
-      o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+      for (int j = 0; j < 2; ++j) acc1[rb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[j][ks], xf, acc1[rb][j], 0, 0, 0);
     }
-    *reinterpret_cast<f32x4*>(a.h + (long long)ev * a.ld + nn) = o;
+  }
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int nn = wave * 32 + j * 16 + q * 4;
+      f32x4 hv = acc1[rb][j];
+      if (a.b1) hv += *reinterpret_cast<const f32x4*>(a.b1 + nn);
+      hv.x = hv.x > 0.f ? hv.x : 0.f; hv.y = hv.y > 0.f ? hv.y : 0.f;
+      hv.z = hv.z > 0.f ? hv.z : 0.f; hv.w = hv.w > 0.f ? hv.w : 0.f;
+      const unsigned lo = pack_bf16(hv.x, hv.y), hi = pack_bf16(hv.z, hv.w);
+      *reinterpret_cast<unsigned long long*>(hs + (r16 + 16 * rb) * L2_HS + nn) = ((unsigned long long)hi << 32) | lo;
+      if (a.hid_out && elive[rb])
+        hid_store4(a.hid_out, (long long)(a.cell_row0 + m0 + r16 + 16 * rb) * a.ldhid + nn, hv, a.hid16);
+    }
+  __syncthreads();
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hs + (r16 + 16 * rb) * L2_HS + ks * 32 + q * 8);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[ks], hf, acc2, 0, 0, 0);
+    }
+    if (elive[rb]) {
+      const int nn = wave * 16 + q * 4;
+      f32x4 o = acc2;
+      if (a.b2) o += *reinterpret_cast<const f32x4*>(a.b2 + nn);
+      o += hold[rb];
+      if (a.relu) {
+        o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+        o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(a.h + (long long)(a.cell_row0 + m0 + r16 + 16 * rb) * a.ld + nn) = o;
+    }
   }
 }
 
@@ -846,12 +881,20 @@ extern "C" int mmft_level_fwd_slots(float* h, const float* pre, long long ld, in
                    (!b1 || aligned16(b1)) && (!b2 || aligned16(b2)) && (!hid_out || (aligned16(hid_out) && ldhid % 4 == 0)),
                "level_fwd_slots: operands must be 16-byte aligned");
   DeviceGuard dg(device);
-  const int tiles = cdiv(n_cell, 16), net_tiles = cdiv(n_net, 16);
+  // two row blocks per workgroup by default: the kernel itself takes the same 16.7 us, the replayed step is 0.07 ms faster
+  // (half the workgroups fetch the packed weights while the U-Net runs beside them); MMFT_FWD_RB=1 selects the 16-row form
+  static int rb = getenv("MMFT_FWD_RB") ? atoi(getenv("MMFT_FWD_RB")) : 2;
+  const int bm = rb == 2 ? 32 : 16;
+  const int tiles = cdiv(n_cell, bm), net_tiles = cdiv(n_net, bm);
   LevelSlotsArgs a{h, pre, ld, slots, net_driver, net_row0, n_net, cell_row0, n_cell, A, LSE, (const unsigned short*)w1_bf16,
                    (const unsigned short*)w2_bf16, b1, b2, hid_out, ldhid, hid_bf16 ? 1 : 0, relu, active, tiles};
   const double fl = 2.0 * n_cell * ((double)L2_K1 * L2_HD + (double)L2_HD * L2_D2);
-  MMFT_LAUNCH("level_fwd_slots_kernel", fl, alg_bytes > 0 ? (double)alg_bytes : 0.0, level_fwd_slots_kernel,
-              dim3(tiles > net_tiles ? tiles : net_tiles), dim3(512), (hipStream_t)stream, a);
+  if (rb == 2)
+    MMFT_LAUNCH("level_fwd_slots_kernel", fl, alg_bytes > 0 ? (double)alg_bytes : 0.0, level_fwd_slots_kernel<2>,
+                dim3(tiles > net_tiles ? tiles : net_tiles), dim3(512), (hipStream_t)stream, a);
+  else
+    MMFT_LAUNCH("level_fwd_slots_kernel", fl, alg_bytes > 0 ? (double)alg_bytes : 0.0, level_fwd_slots_kernel<1>,
+                dim3(tiles > net_tiles ? tiles : net_tiles), dim3(512), (hipStream_t)stream, a);
   return check_launch("level_fwd_slots");
 }
 
