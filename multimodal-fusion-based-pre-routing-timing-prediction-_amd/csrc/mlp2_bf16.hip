@@ -881,9 +881,13 @@ extern "C" int mmft_level_fwd_slots(float* h, const float* pre, long long ld, in
                    (!b1 || aligned16(b1)) && (!b2 || aligned16(b2)) && (!hid_out || (aligned16(hid_out) && ldhid % 4 == 0)),
                "level_fwd_slots: operands must be 16-byte aligned");
   DeviceGuard dg(device);
-  // two 16-row blocks per workgroup by default: the kernel takes the same 16.7 us, the replayed step is 0.06 ms faster (half the
-  // workgroups fetch the packed weights while the U-Net runs beside them); MMFT_FWD_RB=1 selects the 16-row form
-  static int rb = getenv("MMFT_FWD_RB") ? atoi(getenv("MMFT_FWD_RB")) : 2;
+  // two 16-row blocks per workgroup when that still gives every CU a workgroup: the kernel takes the same 16.7 us at config B and
+  // the replayed step is 0.06 ms faster (half the workgroups fetch the packed weights while the U-Net runs beside them); a
+  // small level (config C: 1 250 cell rows = 78 blocks) is bound by the latency of one workgroup and takes 13.8 instead of
+  // 9.7 us in that form.  MMFT_FWD_RB=1 / 2 forces one form.
+  static const int rb_env = getenv("MMFT_FWD_RB") ? atoi(getenv("MMFT_FWD_RB")) : 0;
+  const int rows_max = n_cell > n_net ? n_cell : n_net;
+  const int rb = rb_env ? rb_env : (rows_max >= 32 * 192 ? 2 : 1);
   const int bm = rb == 2 ? 32 : 16;
   const int tiles = cdiv(n_cell, bm), net_tiles = cdiv(n_net, bm);
   LevelSlotsArgs a{h, pre, ld, slots, net_driver, net_row0, n_net, cell_row0, n_cell, A, LSE, (const unsigned short*)w1_bf16,

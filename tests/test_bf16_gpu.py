@@ -244,15 +244,17 @@ def test_training_in_bf16_tracks_fp32(dev):
     assert abs(res['bf16'][1] - res['f32'][1]) < 0.2 * res['f32'][1] + 1e-3
 
 
-def test_fused_level_kernel_equals_two_kernel_form(dev):
+@pytest.mark.parametrize('shape', [(6000, 12), (40000, 8)])
+def test_fused_level_kernel_equals_two_kernel_form(dev, shape):
     """bf16 mode: the three forms of the forward level chain - two kernels (mmft_pair_fwd_gather, then mmft_mlp2_rows_bf16),
     the fused kernel (mmft_level_fwd_bf16) and its slot-table form (mmft_level_fwd_slots: static per-row edge slots, net rows
     inside the cell workgroups, early read-modify-write operand) - run the same instruction sequences per row: bitwise
-    equal embeddings, saved state and gradients."""
+    equal embeddings, saved state and gradients.  Levels of 1 000 rows take the slot kernel's 16-row workgroups, levels of
+    10 000 rows its 32-row workgroups (two blocks per workgroup from 6 144 rows on)."""
     from mmft import sweep as S
     from mmft.synth import synth_design
     from mmft.train import build_models, DesignBatch
-    designs = [synth_design(N=6000, L=12, tile=32, seed=120 + i, end_frac=0.2) for i in range(2)]
+    designs = [synth_design(N=shape[0], L=shape[1], tile=32, seed=120 + i, end_frac=0.2) for i in range(2)]
     b = DesignBatch(designs, dev)
     pmodel, _ = build_models(map_size=designs[0].map_size, device=dev, seed=8)
     ends = b.select([np.arange(0, d.num_paths, 3) for d in designs])[0]
