@@ -7,6 +7,18 @@
 #include <stdarg.h>
 #include "../../include/mmft.h"
 
+// Kernels whose packed-fp32 code would contain v_pk_fma_f32 with a LOW-half source select (`op_sel`: the low result takes the
+// high register of a 64-bit operand pair) are compiled without packed fp32 instructions.  Measured on MI355X (DESIGN §3.7,
+// "packed fma"): fc_prefix_kernel, replayed inside the whole-step HIP graph next to the sweep stream's MFMA kernels, lost the
+// f * w term of one such instruction's low result in 16 lanes in ~5 % of its launches (inputs verified before and after the
+// launch; 0 of 85 runs with plain v_fma_f32, 14 of 68 with the packed form).  tests/test_host_cpu.py checks that no kernel of
+// the built library contains the form.  (The attribute exists on the device pass only.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MMFT_ALLOW_PACKED_OPSEL)      // make EXTRA=-DMMFT_ALLOW_PACKED_OPSEL: the reproducer's build
+#define MMFT_NO_PACKED_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define MMFT_NO_PACKED_F32
+#endif
+
 namespace mmft {
 
 void set_error(const char* fmt, ...);

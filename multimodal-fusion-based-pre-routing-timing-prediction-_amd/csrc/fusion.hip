@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) masked_fc_fwd_kernel(const int* __restric
 // ---- the same projection through block-prefix sums (path masks are unions of boxes = runs of consecutive cells) ----
 // GP[b*P + c][:] = sum over the cells c' <= c of c's block of S consecutive cells of f[b*P + c'] * wT[c'][:].
 // One thread per (design, block, 4-channel group) scans its S cells; the loads do not depend on the running sum.
-__global__ void __launch_bounds__(256) fc_prefix_kernel(const float* __restrict__ f, const float* __restrict__ wT,
+__global__ void __launch_bounds__(256) MMFT_NO_PACKED_F32 fc_prefix_kernel(const float* __restrict__ f, const float* __restrict__ wT,
                                                         float* __restrict__ GP, int B, int P, int Dout, int S) {
   const int groups = Dout >> 2, nblk = P / S;
   const long long total = (long long)B * nblk * groups;

@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256) seg_mean_fwd_kernel(const float* __restri
 
 // FAST: the hardware exponential in the cell-consumer term (bf16 math mode, see fold_gather.h)
 template <bool FAST>
-__global__ void __launch_bounds__(256) level_bwd_pull_kernel(
+__global__ void __launch_bounds__(256) MMFT_NO_PACKED_F32 level_bwd_pull_kernel(
     float* __restrict__ G, const float* __restrict__ h, long long ld, const int* __restrict__ rows, int row0, int n,
     int D, const int* __restrict__ on_ptr, const int* __restrict__ on_idx, const float* __restrict__ on_w,
     const int* __restrict__ oc_ptr, const int* __restrict__ oc_idx, const float* __restrict__ A,

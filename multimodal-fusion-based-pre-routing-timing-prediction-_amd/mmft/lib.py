@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(PKG_DIR, 'lib', 'libmmft_hip.so')
+LIB_PATH = os.environ.get('MMFT_LIB') or os.path.join(PKG_DIR, 'lib', 'libmmft_hip.so')      # MMFT_LIB: another build of the same library (A/B runs)
 HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), 'include', 'mmft.h')
 
 _lib = None

@@ -58,6 +58,8 @@ def parameter_buckets(pmodel, cnn):
     return [('head', head), ('gnn+cnn', rest)]
 
 
+_JOIN_LATE = os.environ.get('MMFT_JOIN_LATE') == '1'      # see TrainStep.forward
+
 class DesignBatch:
     """B designs resident on the device, merged block-diagonally."""
 
@@ -260,15 +262,19 @@ class TrainStep:
             feat = self.cnn(b.images).reshape(b.B, -1) if self.cnn is not None else None
             pm = MaskedPathMap(b.masks, paths_d, feat, foff_d if b.B > 1 else None, *b.links) \
                 if feat is not None else None
-            # The sweep stream is joined BEFORE the masked projection.  Issued ahead of the join (it needs only the CNN output) the
-            # projection overlapped the sweep's last launches, and a replayed graph then occasionally produced other
-            # projection outputs than the eager step (full-size config B, 32-row level kernel: h and the U-Net output bit for
-            # bit equal, h_cnn 1e-2 off; never with the join first) - the two share no buffer this code knows of, so the
-            # overlap is given up: the sweep finishes before the U-Net anyway (tools/step_timeline.py), the join costs nothing.
-            if h_gnn is not None and self.overlap:
+            # The sweep stream is joined BEFORE the masked projection.  Issued ahead of the join (it needs only the CNN output)
+            # the projection's kernels ran beside the sweep's last launches, and in a replayed graph its prefix kernel then lost
+            # one term in ~5 % of the launches - a wrong result of one packed-fma form under that co-residency, not a data race
+            # (csrc/common.h MMFT_NO_PACKED_F32).  The kernel no longer contains the form; the join stays first
+            # because it is free: the sweep finishes before the U-Net anyway (tools/step_timeline.py).  MMFT_JOIN_LATE=1
+            # restores the old order for tools/packed_fma_repro.py.
+            if h_gnn is not None and self.overlap and not _JOIN_LATE:
                 cur.wait_stream(self.side)
                 h_gnn.record_stream(cur)
             h_cnn = self.pmodel._fcn(pm) if (pm is not None and self.pmodel.fcn is not None) else None
+            if h_gnn is not None and self.overlap and _JOIN_LATE:
+                cur.wait_stream(self.side)
+                h_gnn.record_stream(cur)
             return self.pmodel.fuse_heads(h_gnn, pm, lv_d, b.L, h_cnn=h_cnn), ends_d, ends_h
         feat = self.cnn(b.images).reshape(b.B, -1) if self.cnn is not None else None      # src/train.py:465,562
         g.targets_unique = b.ends_unique      # host knowledge: no repeated endpoint -> one exact atomic add per element

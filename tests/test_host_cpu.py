@@ -280,6 +280,31 @@ def test_bench_sec8d_formula():
     assert abs(r['fwd']['frac_of_hbm_peak'] - r['fwd']['achieved_gbs'] / bench.PEAK_HBM_GBS) < 1e-12
 
 
+def test_no_kernel_contains_a_packed_fma_with_low_half_select(tmp_path):
+    """csrc/common.h, MMFT_NO_PACKED_F32: v_pk_*_f32 instructions whose LOW result selects the high register of an operand
+    pair (`op_sel:[...]`, as opposed to the common `op_sel_hi` broadcast) gave wrong results on MI355X when their kernel ran
+    beside another stream's MFMA kernels.  The built library must not contain the form in any kernel."""
+    import glob, os, shutil, subprocess
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not os.path.exists(objdump) or not os.path.exists(lib.LIB_PATH):
+        pytest.skip('needs llvm-objdump and the built library')
+    so = shutil.copy(lib.LIB_PATH, tmp_path / 'libmmft_hip.so')
+    subprocess.run([objdump, '--offloading', str(so)], cwd=tmp_path, check=True, capture_output=True)
+    bundles = glob.glob(str(tmp_path / '*gfx950*'))
+    assert bundles, 'no gfx950 code object in the library'
+    bad, packed, kernel = [], 0, None
+    for b in bundles:
+        for line in subprocess.run([objdump, '-d', b], check=True, capture_output=True, text=True).stdout.splitlines():
+            if line.endswith('>:'):
+                kernel = line.split('<')[-1][:-2]
+            elif 'v_pk_' in line and '_f32' in line:
+                packed += 1
+                if ' op_sel:' in line:
+                    bad.append((kernel, line.strip()[:90]))
+    assert packed > 1000            # packed fp32 math is still what the other kernels use
+    assert not bad, bad
+
+
 def test_every_call_site_matches_the_header():
     """Static check: each `lib.call('mmft_x', ...)` / `lib.query(...)` in the package, the tools, the tests and bench.py passes
     exactly as many arguments as include/mmft.h declares for that entry point (ctypes would only notice on a GPU box)."""
